@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs the compiled reference harness under oracle/_ref")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import prt_testlib as T
+    return T.oracle()
