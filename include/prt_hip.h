@@ -1,0 +1,177 @@
+/*
+ * prt_hip.h -- C-ABI of libprt_hip.so: the MI355X (gfx950) implementation of PRT's per-pixel
+ * path-tracing loop.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * The reference (amada/PRT) has no FFI of its own: its hot path is entered through one C++
+ * call, PathTracer::TraceBlock(Image&, x0,y0,x1,y1, const Scene&, const Camera&, samples)
+ * (path_tracer.h:20, called from main.cpp:146-147), on data owned by Scene/Bvh/Mesh.  The entry
+ * points below are what that call binds to when the loop runs on the GPU; each cites the
+ * reference interface it replaces (file:line under /root/reference/src).  INTEGRATION.md shows the
+ * host-side binding.
+ *
+ * Conventions: every function returns 0 on success or a negative PRT_HIP_E* code;
+ * prt_hip_last_error() gives the message (thread local).  The caller owns all host pointers; the
+ * library copies what it needs during the call.  One context per device; calls on one context are
+ * serialised by the caller; contexts on different devices are independent.
+ */
+#ifndef PRT_HIP_H
+#define PRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_HIP_OK 0
+#define PRT_HIP_ENODEVICE (-1) /* no HIP device / HIP runtime failure: the product has no CPU path */
+#define PRT_HIP_EINVAL (-2)
+#define PRT_HIP_ENOMEM (-3)
+#define PRT_HIP_ELAUNCH (-4)
+#define PRT_HIP_ESTATE (-5)    /* scene or camera not uploaded */
+#define PRT_HIP_ESTACK (-6)    /* traversal stack deeper than 64 entries (reference asserts, bvh.cpp:552) */
+
+#define PRT_HIP_MAX_BVH 8
+
+typedef struct prt_hip_ctx prt_hip_ctx;
+
+/* Material fields the path reads (material.h:30-44).  reflectionType: 0 diffuse, 1 specular,
+ * 2 refraction (material.h:24-28).  diffuseMap/bumpMap index prt_scene_desc.textures, -1 = none. */
+typedef struct {
+    float diffuse[3];
+    float emissive[3];
+    uint32_t reflectionType;
+    uint32_t alphaTest;
+    int32_t diffuseMap;
+    int32_t bumpMap;
+} prt_material;
+
+/* LinearBvhNode (bvh.h:49-60) with the bit-fields widened. */
+typedef struct {
+    float lower[3];
+    float upper[3];
+    uint32_t primOrSecondNodeIndex;
+    uint32_t triVectorIndex;
+    uint32_t primCount; /* 0xf = internal */
+    uint32_t splitAxis;
+} prt_bvh_node;
+
+/* One Bvh and the Mesh it owns (bvh.h:113-119, mesh.h:87-104), as built by Bvh::build. */
+typedef struct {
+    uint32_t nodeCount;
+    const prt_bvh_node* nodes;     /* Bvh::m_nodes, DFS order, first child = i+1 */
+    uint32_t primCount;
+    const uint32_t* primRemapping; /* Bvh::m_primRemapping */
+    uint32_t vertexCount;
+    const uint32_t* indices;       /* 3*primCount */
+    const float* positions;        /* 3*vertexCount */
+    const float* normals;          /* 3*vertexCount or NULL (Mesh::hasVertexNormal) */
+    const float* texcoords;        /* 2*vertexCount or NULL (Mesh::m_hasTexcoord) */
+    uint32_t materialCount;
+    const uint32_t* primMaterial;  /* primCount */
+    const prt_material* materials;
+} prt_mesh_desc;
+
+/* Texture (texture.h:15-24), 8-bit unorm texels, `component` bytes per texel. */
+typedef struct {
+    int32_t width, height, component;
+    const uint8_t* texels;
+} prt_texture_desc;
+
+/* What Scene holds for the path (scene.h:61-71): BVHs in Scene::add order, lights, radius. */
+typedef struct {
+    uint32_t meshCount;
+    const prt_mesh_desc* meshes;
+    uint32_t textureCount;
+    const prt_texture_desc* textures;
+    uint32_t hasDirectionalLight; /* Scene::isLightAvailable(kDirectional) */
+    float lightDir[3];
+    float lightIntensity[3];
+    float radius;                 /* Scene::getRadius() */
+} prt_scene_desc;
+
+/* Camera after Camera::create (camera.h:17-36, 46-53). */
+typedef struct {
+    float pos[3], dir[3], up[3], right[3];
+    uint32_t width, height;
+    float invWidth, invHeight;
+} prt_camera_desc;
+
+/* The literals of the reference's loop, as parameters (SURVEY.md 5 "Config / flags"). */
+typedef struct {
+    uint32_t samples;  /* kSamples, main.cpp:125; a multiple of 8 (path_tracer.cpp:65) */
+    uint32_t maxDepth; /* 14, path_tracer.cpp:124 */
+    uint32_t rrDepth;  /* Russian roulette when depth > rrDepth; 4, path_tracer.cpp:258 */
+    uint32_t seed;     /* per-pixel generator state = lowbias32(x + y*W + seed) | 1 (replaces random.h:15-17) */
+    float exposure;    /* Image::m_exposure, image.cpp:45 */
+    uint32_t tileSize; /* 16, main.cpp:123-124; tile t is rendered when t % nranks == rank */
+    uint32_t rank, nranks;
+    uint32_t countTraffic; /* also count box/triangle/surface/tap events (slower; not for timing) */
+} prt_render_params;
+
+/* stats.h:10-16 + the algorithmic-traffic events of DESIGN.md */
+typedef struct {
+    uint64_t raysTraced;     /* path_tracer.cpp:62,219,242,276 */
+    uint64_t occludedTraced; /* path_tracer.cpp:220,243 */
+    uint64_t nBox, nTri, nHit, nTap, nPx;
+    uint64_t stackOverflow;  /* lanes that needed more than 64 stack entries (must be 0) */
+    double kernelMs;         /* HIP-event time of the last render's kernel */
+} prt_hip_stats;
+
+/* RayHitT (ray.h:182-198) */
+typedef struct {
+    float t, i, j, k;
+    uint32_t primId, meshId;
+} prt_hit;
+
+/* ---- context ---- */
+int prt_hip_device_count(void);
+int prt_hip_create(int device, prt_hip_ctx** out);
+void prt_hip_destroy(prt_hip_ctx* ctx);
+const char* prt_hip_last_error(void);
+/* fills name (<= cap bytes) and the CU count of the context's device */
+int prt_hip_device_info(prt_hip_ctx* ctx, char* name, size_t cap, int* computeUnits);
+
+/* ---- data: replaces the pointers PathTracer reaches through const Scene& / const Camera&
+ *      (scene.h:61-71 -> bvh.h:113-119 -> mesh.h:87-104; camera.h:46-53) ---- */
+int prt_hip_upload_scene(prt_hip_ctx* ctx, const prt_scene_desc* scene);
+int prt_hip_set_camera(prt_hip_ctx* ctx, const prt_camera_desc* camera);
+
+/* ---- the hot path: replaces PathTracer::TraceBlock (path_tracer.cpp:17-33; pixel rectangle
+ * INCLUSIVE as there) + Image::writePixel (image.cpp:44-50).  d_rgb is a DEVICE pointer to
+ * width*height*3 floats (pixel (x,y) at (x + y*width)*3), or NULL for the context's own
+ * framebuffer.  stream is a hipStream_t (NULL = the context's stream).  Asynchronous with respect
+ * to the host when a stream is given; prt_hip_download / prt_hip_get_stats synchronise. ---- */
+int prt_hip_render(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                   const prt_render_params* params, float* d_rgb, void* stream);
+/* copies the rectangle (inclusive) of the context's framebuffer into a host image of the camera's size */
+int prt_hip_download(prt_hip_ctx* ctx, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
+float* prt_hip_framebuffer(prt_hip_ctx* ctx); /* device pointer, width*height*3 floats */
+int prt_hip_get_stats(prt_hip_ctx* ctx, prt_hip_stats* stats);
+
+/* ---- row-level entry points (parity tests of the traversal rows; host pointers) ----
+ * mode 0: Scene::intersect<SingleRayHitPacket,SingleRayPacket>   (scene.cpp:47, bvh.cpp:429 single branch)
+ * mode 1: Scene::intersect<RayHitPacket,RayPacket>               (packet branch; rays in groups of 8, avgDir = sum/8)
+ * mode 2: Scene::occluded<bool,SingleRayPacket>                  (scene.cpp:69, bvh.cpp:576); hit.t = 1 if occluded else 0
+ * mode 3: Scene::occluded<RayPacketMask,RayPacket> with a full mask
+ * n rays (multiple of 8); org/dir are n*3 floats. */
+int prt_hip_trace_rays(prt_hip_ctx* ctx, int mode, uint32_t n, const float* org, const float* dir, float maxT,
+                       prt_hit* hits);
+/* leaf math on the device (triangle.cpp:90-166, vecmath.h:1402-1518, ray.h:26-71).  in: 22 floats per record =
+ * org[3] dir[3] p0[3] p1[3] p2[3] lower[3] upper[3] maxT; out: 24 floats = [0..3] t,i,j,k with SoaRay::prepare swaps,
+ * [4..7] with Ray::prepare swaps, [12] box t, [13] box bool(maxT), [14] box SoA mask(maxT), [16..18] invDir,
+ * [19..22] swapXZ/swapYZ (SoA), swapXZ/swapYZ (single) */
+int prt_hip_test_leaf(prt_hip_ctx* ctx, uint32_t n, const float* records, float* out);
+/* sin/cos of theta[i] as the kernels compute them (prt_devmath.h) */
+int prt_hip_test_sincos(prt_hip_ctx* ctx, uint32_t n, const float* theta, float* sin_out, float* cos_out);
+/* powf(x, 2.2f) as material.cpp:24-28 (degamma) needs it */
+int prt_hip_test_powf(prt_hip_ctx* ctx, uint32_t n, const float* x, float* y);
+/* Camera::GenerateJitteredRayPacket + Random on the device: out = 8 x {org[3] dir[3] invDir[3] swapXZ swapYZ},
+ * avgDir[3], state after (as float bits) = 92 floats */
+int prt_hip_test_camera(prt_hip_ctx* ctx, uint32_t x, uint32_t y, uint32_t state, float* out92);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1390,3 +1390,15 @@ void orc_render(const orc_scene* scene, const orc_camera* cam, uint32_t samples,
     }
     if (st) *st = total;
 }
+
+/* ------------------------------------------------------------------ libm as the reference calls it
+ * (path_tracer.cpp:153,184 cosf/sinf; material.cpp:27 powf(x, 2.2f)) -- checker for the kernels' own versions */
+void orc_libm_sincos(uint32_t n, const float* theta, float* s, float* c)
+{
+    for (uint32_t i = 0; i < n; i++) { s[i] = sinf(theta[i]); c[i] = cosf(theta[i]); }
+}
+
+void orc_libm_powf22(uint32_t n, const float* x, float* y)
+{
+    for (uint32_t i = 0; i < n; i++) y[i] = powf(x[i], 2.2f);
+}

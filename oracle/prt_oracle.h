@@ -155,6 +155,10 @@ void orc_x_sample_bump(const float normal[3], int32_t w, int32_t h, int32_t comp
                        const float uv[2], const float duv01[2], const float duv02[2], const float dp01[3],
                        const float dp02[3], float out[3]);
 
+/* libm exactly as the reference calls it (checker for the kernels' own sincos / powf) */
+void orc_libm_sincos(uint32_t n, const float* theta, float* s, float* c);
+void orc_libm_powf22(uint32_t n, const float* x, float* y);
+
 #ifdef __cplusplus
 }
 #endif

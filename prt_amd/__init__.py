@@ -1,0 +1,467 @@
+"""prt_amd -- Python host for the MI355X path-tracing hot path.
+
+The product is libprt_hip.so (hand-written HIP kernels for gfx950 + the C++ host classes that
+mirror the reference's Scene/Camera/Mesh/Bvh/Image/PathTracer surface).  This module is the thin
+Python mirror of that surface over ctypes: same names, same argument meaning, used by the tests,
+bench.py and __graft_entry__.  There is no CPU rendering path here: without the HIP library or a
+GPU the render calls raise.
+
+Reference citations (file:line under /root/reference/src) are in include/prt_hip.h and prt_host.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprt_hip.so")
+
+
+class PrtError(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- C structs (include/prt_hip.h)
+class Material(C.Structure):
+    _fields_ = [("diffuse", C.c_float * 3), ("emissive", C.c_float * 3), ("reflectionType", C.c_uint32),
+                ("alphaTest", C.c_uint32), ("diffuseMap", C.c_int32), ("bumpMap", C.c_int32)]
+
+    DIFFUSE, SPECULAR, REFRACTION = 0, 1, 2
+
+    @classmethod
+    def make(cls, diffuse=(0, 0, 0), emissive=(0, 0, 0), reflection=0):
+        m = cls()
+        m.diffuse[:] = [float(x) for x in diffuse]
+        m.emissive[:] = [float(x) for x in emissive]
+        m.reflectionType = reflection
+        m.alphaTest = 0
+        m.diffuseMap = -1
+        m.bumpMap = -1
+        return m
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("lower", C.c_float * 3), ("upper", C.c_float * 3), ("primOrSecondNodeIndex", C.c_uint32),
+                ("triVectorIndex", C.c_uint32), ("primCount", C.c_uint32), ("splitAxis", C.c_uint32)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("nodeCount", C.c_uint32), ("nodes", C.POINTER(BvhNode)), ("primCount", C.c_uint32),
+                ("primRemapping", C.POINTER(C.c_uint32)), ("vertexCount", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
+                ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
+                ("materialCount", C.c_uint32), ("primMaterial", C.POINTER(C.c_uint32)), ("materials", C.POINTER(Material))]
+
+
+class TextureDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("component", C.c_int32), ("texels", C.POINTER(C.c_uint8))]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("meshCount", C.c_uint32), ("meshes", C.POINTER(MeshDesc)), ("textureCount", C.c_uint32),
+                ("textures", C.POINTER(TextureDesc)), ("hasDirectionalLight", C.c_uint32), ("lightDir", C.c_float * 3),
+                ("lightIntensity", C.c_float * 3), ("radius", C.c_float)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("invWidth", C.c_float), ("invHeight", C.c_float)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("samples", C.c_uint32), ("maxDepth", C.c_uint32), ("rrDepth", C.c_uint32), ("seed", C.c_uint32),
+                ("exposure", C.c_float), ("tileSize", C.c_uint32), ("rank", C.c_uint32), ("nranks", C.c_uint32),
+                ("countTraffic", C.c_uint32)]
+
+
+class HipStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx",
+                                          "stackOverflow")] + [("kernelMs", C.c_double)]
+
+    def as_dict(self):
+        return {n: (float(getattr(self, n)) if n == "kernelMs" else int(getattr(self, n))) for n, _ in self._fields_}
+
+
+class Hit(C.Structure):
+    _fields_ = [("t", C.c_float), ("i", C.c_float), ("j", C.c_float), ("k", C.c_float), ("primId", C.c_uint32),
+                ("meshId", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("i", "<f4"), ("j", "<f4"), ("k", "<f4"), ("primId", "<u4"), ("meshId", "<u4")])
+NODE_DTYPE = np.dtype([("lower", "<f4", 3), ("upper", "<f4", 3), ("primOrSecondNodeIndex", "<u4"),
+                       ("triVectorIndex", "<u4"), ("primCount", "<u4"), ("splitAxis", "<u4")])
+MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("reflectionType", "<u4"),
+                           ("alphaTest", "<u4"), ("diffuseMap", "<i4"), ("bumpMap", "<i4")])
+
+# every symbol include/prt_hip.h and include/prt_host.h declare
+EXPORTS = [
+    "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
+    "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_download", "prt_hip_framebuffer",
+    "prt_hip_get_stats", "prt_hip_trace_rays", "prt_hip_test_leaf", "prt_hip_test_sincos", "prt_hip_test_powf",
+    "prt_hip_test_camera",
+    "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
+    "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
+    "prt_host_mesh_calculate_bounds", "prt_host_mesh_prim_count", "prt_host_scene_create", "prt_host_scene_destroy",
+    "prt_host_scene_add_mesh", "prt_host_scene_set_directional_light", "prt_host_scene_describe", "prt_host_scene_bbox",
+    "prt_host_camera_create", "prt_host_bvh_build", "prt_host_free",
+]
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libprt_hip.so for gfx950 with hipcc (in tree)."""
+    return _build.build_library(force=force)
+
+
+def lib():
+    """Load libprt_hip.so.  Fails loudly when it has not been built: the HIP library IS the product."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PrtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950).  prt_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    L.prt_hip_last_error.restype = C.c_char_p
+    L.prt_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.prt_hip_destroy.argtypes = [vp]
+    L.prt_hip_destroy.restype = None
+    L.prt_hip_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.prt_hip_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.prt_hip_set_camera.argtypes = [vp, C.POINTER(CameraDesc)]
+    L.prt_hip_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RenderParams), vp, vp]
+    L.prt_hip_download.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.prt_hip_framebuffer.restype = vp
+    L.prt_hip_framebuffer.argtypes = [vp]
+    L.prt_hip_get_stats.argtypes = [vp, C.POINTER(HipStats)]
+    L.prt_hip_trace_rays.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_float, vp]
+    L.prt_hip_test_leaf.argtypes = [vp, C.c_uint32, vp, vp]
+    L.prt_hip_test_sincos.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.prt_hip_test_powf.argtypes = [vp, C.c_uint32, vp, vp]
+    L.prt_hip_test_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    for n in ("prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
+              "prt_host_mesh_atrium", "prt_host_scene_create"):
+        getattr(L, n).restype = vp
+    L.prt_host_mesh_cornell.argtypes = [C.c_int]
+    L.prt_host_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(Material)]
+    L.prt_host_mesh_from_arrays.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.prt_host_mesh_displaced_sphere.argtypes = [C.c_uint32, C.c_float, f32p, C.POINTER(Material), C.c_uint32]
+    L.prt_host_mesh_atrium.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_float]
+    L.prt_host_mesh_destroy.argtypes = [vp]
+    L.prt_host_mesh_destroy.restype = None
+    L.prt_host_mesh_transform.argtypes = [vp, C.c_float, f32p]
+    L.prt_host_mesh_transform.restype = None
+    L.prt_host_mesh_calculate_vertex_normals.argtypes = [vp]
+    L.prt_host_mesh_calculate_vertex_normals.restype = None
+    L.prt_host_mesh_calculate_bounds.argtypes = [vp]
+    L.prt_host_mesh_calculate_bounds.restype = None
+    L.prt_host_mesh_prim_count.argtypes = [vp]
+    L.prt_host_mesh_prim_count.restype = C.c_uint32
+    L.prt_host_scene_destroy.argtypes = [vp]
+    L.prt_host_scene_destroy.restype = None
+    L.prt_host_scene_add_mesh.argtypes = [vp, vp]
+    L.prt_host_scene_set_directional_light.argtypes = [vp, f32p, f32p]
+    L.prt_host_scene_set_directional_light.restype = None
+    L.prt_host_scene_describe.argtypes = [vp]
+    L.prt_host_scene_describe.restype = C.POINTER(SceneDesc)
+    L.prt_host_scene_bbox.argtypes = [vp, f32p]
+    L.prt_host_scene_bbox.restype = None
+    L.prt_host_camera_create.argtypes = [f32p, f32p, C.c_uint32, C.c_uint32, C.POINTER(CameraDesc)]
+    L.prt_host_camera_create.restype = None
+    L.prt_host_bvh_build.argtypes = [C.c_uint32, vp, vp, C.c_int, C.POINTER(C.POINTER(BvhNode)), u32p, C.POINTER(u32p)]
+    L.prt_host_free.argtypes = [vp]
+    L.prt_host_free.restype = None
+    _lib = L
+    return L
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise PrtError(f"{what} failed ({rc}): {lib().prt_hip_last_error().decode()}")
+
+
+# ----------------------------------------------------------------------------- host mirror
+class Mesh:
+    """prt::Mesh (mesh.h:30-105) before it is handed to a Bvh."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise PrtError("mesh creation failed")
+        self._h = handle
+
+    @classmethod
+    def cornell_box(cls, box=True):
+        return cls(lib().prt_host_mesh_cornell(int(box)))
+
+    @classmethod
+    def load_obj(cls, path, material=None):
+        return cls(lib().prt_host_mesh_load_obj(os.fsencode(path), C.byref(material) if material is not None else None))
+
+    @classmethod
+    def from_arrays(cls, indices, positions, prim_material, materials, normals=None, texcoords=None):
+        indices = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        prim_material = np.ascontiguousarray(prim_material, dtype=np.uint32)
+        materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        n = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+        t = None if texcoords is None else np.ascontiguousarray(texcoords, dtype=np.float32)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        return cls(lib().prt_host_mesh_from_arrays(len(indices), len(positions), len(materials), p(indices), p(positions), p(n),
+                                                   p(t), p(prim_material), p(materials)))
+
+    @classmethod
+    def displaced_sphere(cls, target_tris, radius, center, material, seed=1):
+        return cls(lib().prt_host_mesh_displaced_sphere(target_tris, radius, _f3(center), C.byref(material), seed))
+
+    @classmethod
+    def atrium(cls, target_tris, seed=1, alpha_masked=True, bump_mapped=True, emissive_fraction=0.0):
+        return cls(lib().prt_host_mesh_atrium(target_tris, seed, int(alpha_masked), int(bump_mapped), emissive_fraction))
+
+    def transform(self, scale, translate):
+        lib().prt_host_mesh_transform(self._h, scale, _f3(translate))
+
+    def calculate_vertex_normals(self):
+        lib().prt_host_mesh_calculate_vertex_normals(self._h)
+
+    def calculate_bounds(self):
+        lib().prt_host_mesh_calculate_bounds(self._h)
+
+    @property
+    def prim_count(self):
+        return lib().prt_host_mesh_prim_count(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().prt_host_mesh_destroy(self._h)
+            self._h = None
+
+
+class Scene:
+    """prt::Scene (scene.h:11-73) owning its Bvhs."""
+
+    def __init__(self):
+        self._h = lib().prt_host_scene_create()
+
+    def add(self, mesh):
+        """Bvh::build(std::move(mesh)) + Scene::add(bvh) (main.cpp:24-26)."""
+        _check(lib().prt_host_scene_add_mesh(self._h, mesh._h), "prt_host_scene_add_mesh")
+        mesh._h = None
+
+    def set_directional_light(self, direction, intensity):
+        lib().prt_host_scene_set_directional_light(self._h, _f3(direction), _f3(intensity))
+
+    def describe(self):
+        return lib().prt_host_scene_describe(self._h)
+
+    def bbox(self):
+        b = (C.c_float * 6)()
+        lib().prt_host_scene_bbox(self._h, b)
+        return np.array(b[:], dtype=np.float32)
+
+    def arrays(self):
+        """numpy copies of everything the descriptor points to (for checkers)."""
+        d = self.describe().contents
+        out = dict(meshes=[], textures=[], has_light=bool(d.hasDirectionalLight), light_dir=np.array(d.lightDir[:], dtype=np.float32),
+                   light_intensity=np.array(d.lightIntensity[:], dtype=np.float32), radius=np.float32(d.radius))
+        for i in range(d.meshCount):
+            m = d.meshes[i]
+            as_np = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).view(dt).copy()  # noqa: E731
+            out["meshes"].append(dict(
+                nodes=np.frombuffer(C.string_at(m.nodes, m.nodeCount * C.sizeof(BvhNode)), dtype=NODE_DTYPE).copy(),
+                remap=as_np(m.primRemapping, m.primCount, np.uint32),
+                indices=as_np(m.indices, m.primCount * 3, np.uint32).reshape(-1, 3),
+                positions=as_np(m.positions, m.vertexCount * 3, np.float32).reshape(-1, 3),
+                normals=as_np(m.normals, m.vertexCount * 3, np.float32).reshape(-1, 3) if m.normals else None,
+                texcoords=as_np(m.texcoords, m.vertexCount * 2, np.float32).reshape(-1, 2) if m.texcoords else None,
+                prim_material=as_np(m.primMaterial, m.primCount, np.uint32),
+                materials=np.frombuffer(C.string_at(m.materials, m.materialCount * C.sizeof(Material)), dtype=MATERIAL_DTYPE).copy()))
+        for i in range(d.textureCount):
+            t = d.textures[i]
+            out["textures"].append(np.ctypeslib.as_array(t.texels, shape=(t.height, t.width, t.component)).copy())
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().prt_host_scene_destroy(self._h)
+            self._h = None
+
+
+class Camera:
+    """prt::Camera (camera.h:14-53)."""
+
+    def __init__(self):
+        self.desc = CameraDesc()
+
+    def create(self, pos, direction, width, height):
+        lib().prt_host_camera_create(_f3(pos), _f3(direction), width, height, C.byref(self.desc))
+        return self
+
+    @property
+    def width(self):
+        return self.desc.width
+
+    @property
+    def height(self):
+        return self.desc.height
+
+
+class PathTracer:
+    """prt::PathTracer (path_tracer.h:15-38) bound to one GPU through the C-ABI (include/prt_hip.h)."""
+
+    def __init__(self, device=0, max_depth=14, rr_depth=4, seed=12345):
+        L = lib()
+        self._ctx = C.c_void_p()
+        _check(L.prt_hip_create(device, C.byref(self._ctx)), "prt_hip_create")
+        self.max_depth, self.rr_depth, self.seed = max_depth, rr_depth, seed
+        self._scene = None
+        self._camera = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib().prt_hip_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        _check(lib().prt_hip_device_info(self._ctx, name, 256, C.byref(cus)), "prt_hip_device_info")
+        return name.value.decode(), cus.value
+
+    def upload_scene(self, scene):
+        _check(lib().prt_hip_upload_scene(self._ctx, scene.describe()), "prt_hip_upload_scene")
+        self._scene = scene
+
+    def set_camera(self, camera):
+        _check(lib().prt_hip_set_camera(self._ctx, C.byref(camera.desc)), "prt_hip_set_camera")
+        self._camera = camera
+
+    def params(self, samples, exposure=1.0, rank=0, nranks=1, count_traffic=False, max_depth=None, tile=16):
+        p = RenderParams()
+        p.samples = samples
+        p.maxDepth = self.max_depth if max_depth is None else max_depth
+        p.rrDepth = self.rr_depth
+        p.seed = self.seed
+        p.exposure = exposure
+        p.tileSize = tile
+        p.rank, p.nranks = rank, nranks
+        p.countTraffic = int(count_traffic)
+        return p
+
+    def render_async(self, x0, y0, x1, y1, samples, d_rgb=None, stream=None, **kw):
+        """PathTracer::TraceBlock on the GPU; d_rgb = device pointer (int) or None for the context framebuffer."""
+        p = self.params(samples, **kw)
+        _check(lib().prt_hip_render(self._ctx, x0, y0, x1, y1, C.byref(p), d_rgb, stream), "prt_hip_render")
+
+    def trace_block(self, x0, y0, x1, y1, samples, **kw):
+        """Render the inclusive rectangle and return it as a (h, w, 3) float32 array."""
+        self.render_async(x0, y0, x1, y1, samples, **kw)
+        W, H = self._camera.width, self._camera.height
+        img = np.zeros((H, W, 3), dtype=np.float32)
+        _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        self.stats()  # raises on stack overflow
+        return img[y0:y1 + 1, x0:x1 + 1].copy()
+
+    def render(self, samples, **kw):
+        W, H = self._camera.width, self._camera.height
+        return self.trace_block(0, 0, W - 1, H - 1, samples, **kw)
+
+    def stats(self):
+        st = HipStats()
+        _check(lib().prt_hip_get_stats(self._ctx, C.byref(st)), "prt_hip_get_stats")
+        return st.as_dict()
+
+    # ---- row-level entry points (parity tests)
+    def trace_rays(self, mode, org, dirs, max_t):
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        hits = np.zeros(len(org), dtype=HIT_DTYPE)
+        _check(lib().prt_hip_trace_rays(self._ctx, mode, len(org), org.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p),
+                                        max_t, hits.ctypes.data_as(C.c_void_p)), "prt_hip_trace_rays")
+        return hits
+
+    def test_leaf(self, records):
+        rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 22)
+        out = np.zeros((len(rec), 24), dtype=np.float32)
+        _check(lib().prt_hip_test_leaf(self._ctx, len(rec), rec.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "prt_hip_test_leaf")
+        return out
+
+    def test_sincos(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float32)
+        s, c = np.zeros_like(th), np.zeros_like(th)
+        _check(lib().prt_hip_test_sincos(self._ctx, len(th), th.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                         c.ctypes.data_as(C.c_void_p)), "prt_hip_test_sincos")
+        return s, c
+
+    def test_powf(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.zeros_like(x)
+        _check(lib().prt_hip_test_powf(self._ctx, len(x), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)), "prt_hip_test_powf")
+        return y
+
+    def test_camera(self, x, y, state):
+        out = np.zeros(92, dtype=np.float32)
+        _check(lib().prt_hip_test_camera(self._ctx, x, y, state, out.ctypes.data_as(C.c_void_p)), "prt_hip_test_camera")
+        return out
+
+
+def device_count():
+    return lib().prt_hip_device_count()
+
+
+# ----------------------------------------------------------------------------- the reference's scene setups (main.cpp:22-105)
+def setup_cornell_box(width, height, teapot_obj=None, teapot_mesh=None):
+    """setupCornellBox (main.cpp:22-55).  The teapot comes from an OBJ file or from a ready Mesh."""
+    scene = Scene()
+    scene.add(Mesh.cornell_box(True))
+    if teapot_obj is not None:
+        teapot_mesh = Mesh.load_obj(teapot_obj, Material.make(diffuse=(0.9, 0.9, 0.9), reflection=Material.SPECULAR))
+        teapot_mesh.transform(0.005, (-0.5, 0.0, 0.5))
+    if teapot_mesh is not None:
+        teapot_mesh.calculate_vertex_normals()
+        teapot_mesh.calculate_bounds()
+        scene.add(teapot_mesh)
+    camera = Camera().create((0, 0.965, 2.6), (0, 0, -1.0), width, height)
+    return scene, camera, 1.0
+
+
+def _normalize(v):
+    v = np.asarray(v, dtype=np.float32)
+    d = np.float32(v[0] * v[0]) + np.float32(v[1] * v[1]) + np.float32(v[2] * v[2])
+    inv = np.float32(1.0) / np.sqrt(np.float32(d), dtype=np.float32)
+    return (inv * v).astype(np.float32)
+
+
+def setup_bunny_standin(width, height, tris=69451, seed=1):
+    """BASELINE config 2 stand-in: Cornell box + a bunny-class displaced sphere (69 451 triangles
+    asked for; a lat-long grid gives the nearest even count) in place of the teapot, plus the directional light of
+    setupSanMiguelLowPoly (main.cpp:84) so that occlusion rays are exercised."""
+    scene = Scene()
+    scene.add(Mesh.cornell_box(True))
+    m = Mesh.displaced_sphere(tris, 0.3, (-0.45, 0.36, 0.45), Material.make(diffuse=(0.8, 0.75, 0.7)), seed)
+    m.calculate_vertex_normals()
+    m.calculate_bounds()
+    scene.add(m)
+    scene.set_directional_light(_normalize((0.2, 1.0, 0.2)), (16.7, 15.6, 11.7))
+    camera = Camera().create((0, 0.965, 2.6), (0, 0, -1.0), width, height)
+    return scene, camera, 1.0
+
+
+def setup_atrium_standin(width, height, tris=262000, seed=1, alpha=True, bump=True, emissive_fraction=0.0, light=True):
+    """BASELINE config 3 stand-in: Sponza-class atrium, light as setupSponza (main.cpp:66)."""
+    scene = Scene()
+    m = Mesh.atrium(tris, seed, alpha, bump, emissive_fraction)
+    m.calculate_vertex_normals()
+    scene.add(m)
+    if light:
+        scene.set_directional_light(_normalize((0.05, 1.0, 0.1)), (16.7, 15.6, 11.7))
+    camera = Camera().create((-15.0, 4.0, 0.5), (1.0, 0.08, -0.05), width, height)
+    return scene, camera, 1.0

@@ -1,0 +1,412 @@
+// prt_host.cpp -- host-side classes behind prt.h: scene bookkeeping, camera set-up, image
+// container, thread pool and PathTracer::TraceBlock (the single entry into the GPU hot path).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+#include "prt.h"
+
+namespace prt
+{
+
+void logPrintf(LogLevel level, const char* format...)
+{
+    if (level == LogLevel::kError) printf("ERROR: ");
+    va_list args;
+    va_start(args, format);
+    vfprintf(stdout, format, args);
+    va_end(args);
+}
+
+// ---------------------------------------------------------------- texture / material
+void Texture::create(uint16_t w, uint16_t h, uint8_t comp, const uint8_t* data)
+{
+    width = w;
+    height = h;
+    component = comp;
+    texels = std::make_shared<std::vector<uint8_t>>(data, data + (size_t)w * h * comp);
+}
+
+bool Texture::isAlphaTestRequired() const // texture.cpp:338-350
+{
+    if (!isValid() || component != 4) return false;
+    for (size_t i = 0; i < (size_t)width * height; ++i)
+        if ((*texels)[i * 4 + 3] < 255) return true;
+    return false;
+}
+
+void Material::init() // material.cpp:30-43
+{
+    diffuse = Vector3f(0.0f);
+    ambient = Vector3f(0.0f);
+    specular = Vector3f(0.0f);
+    emissive = Vector3f(0.0f);
+    diffuseMap.init();
+    ambientMap.init();
+    specularMap.init();
+    emissiveMap.init();
+    bumpMap.init();
+    reflectionType = ReflectionType::kDiffuse;
+    alphaTest = false;
+}
+
+// ---------------------------------------------------------------- mesh
+void Mesh::create(uint32_t primCount, uint32_t vertexCount, uint32_t materialCount, bool hasVertexNormal)
+{
+    m_indices.assign((size_t)primCount * kVertexCountPerPrim, 0);
+    m_positions.assign(vertexCount, Vector3f(0.0f));
+    m_texcoords.assign(vertexCount, Vector2f(0.0f));
+    m_normals.clear();
+    if (hasVertexNormal) m_normals.assign(vertexCount, Vector3f(0.0f));
+    m_primMaterial.assign(primCount, 0);
+    m_materials.resize(materialCount);
+    for (auto& m : m_materials) m.init();
+    m_hasVertexNormal = hasVertexNormal;
+    m_hasTexcoord = false;
+}
+
+// mesh.cpp:108-149: prims in reverse order; an accumulated normal is never allowed to become zero
+void Mesh::calculateVertexNormals()
+{
+    const uint32_t vertexCount = getVertexCount();
+    m_normals.assign(vertexCount, Vector3f(0.0f));
+    for (int32_t i = (int32_t)getPrimCount() - 1; i >= 0; i--) {
+        uint32_t v[3];
+        Vector3f p[3];
+        for (uint32_t j = 0; j < 3; j++) {
+            v[j] = m_indices[3 * i + j];
+            p[j] = m_positions[v[j]];
+        }
+        auto normal = normalize(cross(p[1] - p[0], p[2] - p[0]));
+        if (std::isnan(normal.x) || std::isnan(normal.y) || std::isnan(normal.z)) normal.set(0.0f, 0.0f, 0.0f);
+        for (uint32_t j = 0; j < 3; j++) {
+            auto n = m_normals[v[j]] + normal;
+            if (length(n) > 0.0f) m_normals[v[j]] = n;
+        }
+    }
+    for (uint32_t i = 0; i < vertexCount; i++) m_normals[i] = normalize(m_normals[i]);
+    m_hasVertexNormal = true;
+}
+
+void Mesh::calculateBounds() // mesh.cpp:302-309
+{
+    BBox bbox = BBox::init();
+    for (const auto& p : m_positions) bbox.merge(p);
+    m_bbox = bbox;
+}
+
+// ---------------------------------------------------------------- scene (scene.cpp:9-27)
+void Scene::init()
+{
+    m_directionalLight.init();
+    m_availableLights = 0;
+    m_bbox = BBox::init();
+    m_radius = std::numeric_limits<float>::max();
+    m_bvh.clear();
+    m_revision++;
+}
+
+void Scene::add(Bvh* bvh)
+{
+    bvh->m_mesh.m_id = (uint32_t)m_bvh.size();
+    m_bvh.push_back(bvh);
+    m_bbox.merge(bvh->m_mesh.getBBox());
+    auto center = m_bbox.center();
+    m_radius = length(m_bbox.upper - center);
+    m_revision++;
+}
+
+void Scene::setDirectionalLight(const Vector3f& dir, const Vector3f& intensity) // scene.h:30-35
+{
+    m_directionalLight = {dir, intensity};
+    m_availableLights |= (1u << (uint32_t)LightType::kDirectional);
+    m_availableLights &= ~(1u << (uint32_t)LightType::kInfiniteArea);
+    m_revision++;
+}
+
+void Scene::setInfiniteAreaLight(const char* path)
+{
+    logPrintf(LogLevel::kError, "InfiniteAreaLight '%s' is not on the GPU path yet (SURVEY.md 8f.1); ignored\n", path);
+}
+
+void Scene::describe(prt_scene_desc& desc, DescStorage& store) const
+{
+    store.meshes.clear();
+    store.materials.clear();
+    store.textures.clear();
+    store.texelRefs.clear();
+    std::map<const std::vector<uint8_t>*, int32_t> texIndex;
+    auto addTex = [&](const Texture& t) -> int32_t {
+        if (!t.isValid()) return -1;
+        auto it = texIndex.find(t.texels.get());
+        if (it != texIndex.end()) return it->second;
+        prt_texture_desc d{(int32_t)t.width, (int32_t)t.height, (int32_t)t.component, t.texels->data()};
+        store.textures.push_back(d);
+        store.texelRefs.push_back(t.texels);
+        int32_t id = (int32_t)store.textures.size() - 1;
+        texIndex[t.texels.get()] = id;
+        return id;
+    };
+    store.materials.resize(m_bvh.size());
+    for (size_t b = 0; b < m_bvh.size(); b++) {
+        const Bvh* bvh = m_bvh[b];
+        const Mesh& m = bvh->m_mesh;
+        auto& mats = store.materials[b];
+        for (uint32_t k = 0; k < m.getMaterialCount(); k++) {
+            const Material& s = m.getMaterial(k);
+            prt_material d;
+            memcpy(d.diffuse, &s.diffuse, 12);
+            memcpy(d.emissive, &s.emissive, 12);
+            d.reflectionType = (uint32_t)s.reflectionType;
+            d.alphaTest = s.alphaTest ? 1u : 0u;
+            d.diffuseMap = addTex(s.diffuseMap);
+            d.bumpMap = addTex(s.bumpMap);
+            mats.push_back(d);
+        }
+        prt_mesh_desc md;
+        md.nodeCount = (uint32_t)bvh->m_nodes.size();
+        md.nodes = bvh->m_nodes.data();
+        md.primCount = m.getPrimCount();
+        md.primRemapping = bvh->m_primRemapping.data();
+        md.vertexCount = m.getVertexCount();
+        md.indices = m.m_indices.data();
+        md.positions = &m.m_positions[0].x;
+        md.normals = m.hasVertexNormal() ? &m.m_normals[0].x : nullptr;
+        md.texcoords = m.hasTexcoord() ? &m.m_texcoords[0].x : nullptr;
+        md.materialCount = m.getMaterialCount();
+        md.primMaterial = m.m_primMaterial.data();
+        md.materials = mats.data();
+        store.meshes.push_back(md);
+    }
+    desc.meshCount = (uint32_t)store.meshes.size();
+    desc.meshes = store.meshes.data();
+    desc.textureCount = (uint32_t)store.textures.size();
+    desc.textures = store.textures.data();
+    desc.hasDirectionalLight = isLightAvailable(LightType::kDirectional) ? 1u : 0u;
+    memcpy(desc.lightDir, &m_directionalLight.dir, 12);
+    memcpy(desc.lightIntensity, &m_directionalLight.intensity, 12);
+    desc.radius = m_radius;
+}
+
+// ---------------------------------------------------------------- camera (camera.h:17-36)
+void Camera::create(const Vector3f& pos, const Vector3f& dir, uint32_t width, uint32_t height)
+{
+    m_pos = pos;
+    m_dir = normalize(dir);
+    m_width = width;
+    m_height = height;
+    m_invWidth = 1.0f / width;
+    m_invHeight = 1.0f / height;
+    auto up = Vector3f(0, 1.0f, 0);
+    auto right = cross(dir, up);
+    if (length(right) < 0.00001f) right = cross(dir, Vector3f(1, 0, 0));
+    right = normalize(right);
+    up = normalize(cross(right, dir));
+    m_up = up;
+    m_right = right;
+}
+
+void Camera::describe(prt_camera_desc& d) const
+{
+    memcpy(d.pos, &m_pos, 12);
+    memcpy(d.dir, &m_dir, 12);
+    memcpy(d.up, &m_up, 12);
+    memcpy(d.right, &m_right, 12);
+    d.width = m_width;
+    d.height = m_height;
+    d.invWidth = m_invWidth;
+    d.invHeight = m_invHeight;
+}
+
+// ---------------------------------------------------------------- image (image.cpp:29-80)
+Image::Image(uint32_t width, uint32_t height, bool tonemap, float exposure)
+    : m_pixels((size_t)3 * width * height, 0.0f), m_width(width), m_height(height), m_tonemap(tonemap), m_exposure(exposure)
+{
+}
+
+void Image::writePixel(uint32_t x, uint32_t y, const Vector3f& color)
+{
+    auto c = m_exposure * color;
+    const size_t indexBase = ((size_t)x + (size_t)y * m_width) * 3;
+    m_pixels[indexBase + 0] = c.x;
+    m_pixels[indexBase + 1] = c.y;
+    m_pixels[indexBase + 2] = c.z;
+}
+
+void Image::savePpm(const char* path) const
+{
+    FILE* fp = fopen(path, "wb");
+    if (!fp) {
+        printf("Error saving %s\n", path);
+        return;
+    }
+    std::vector<uint8_t> pixels((size_t)3 * m_width * m_height);
+    for (size_t i = 0; i < (size_t)m_width * m_height; i++) {
+        for (int k = 0; k < 3; k++) {
+            float c = m_pixels[3 * i + k];
+            c = m_tonemap ? c / (c + 1) : c;                 // image.cpp:64
+            c = std::fmin(std::fmax(c, 0.0f), 1.0f);
+            pixels[3 * i + k] = (uint8_t)(powf(c, 1 / 2.2f) * 0xff); // image.cpp:65
+        }
+    }
+    fprintf(fp, "P6\n%d %d\n255\n", m_width, m_height);
+    fwrite(pixels.data(), pixels.size(), 1, fp);
+    fclose(fp);
+    printf("Save %s\n", path);
+}
+
+void Image::savePfm(const char* path) const
+{
+    FILE* fp = fopen(path, "wb");
+    if (!fp) {
+        printf("Error saving %s\n", path);
+        return;
+    }
+    fprintf(fp, "PF\n%d %d\n-1.0\n", m_width, m_height);
+    for (int32_t y = (int32_t)m_height - 1; y >= 0; y--) fwrite(&m_pixels[(size_t)y * m_width * 3], 4, (size_t)m_width * 3, fp);
+    fclose(fp);
+    printf("Save %s\n", path);
+}
+
+void Image::saveExr(const char* path) const
+{
+    // image.cpp:82-139 writes half-float EXR through tinyexr (not vendored).  Raw float PFM keeps full precision.
+    std::string p = std::string(path) + ".pfm";
+    savePfm(p.c_str());
+}
+
+// ---------------------------------------------------------------- thread pool (thread_pool.cpp)
+struct ThreadPool::Impl {
+    std::deque<Task> tasks;
+    std::mutex mutex;
+    std::condition_variable cond;
+    std::vector<std::thread> workers;
+    bool alive = false;
+    void run()
+    {
+        for (;;) {
+            Task task;
+            {
+                std::unique_lock<std::mutex> g(mutex);
+                cond.wait(g, [&] { return !tasks.empty() || !alive; });
+                if (tasks.empty()) return;
+                task = std::move(tasks.back()); // LIFO, thread_pool.cpp:77-78
+                tasks.pop_back();
+            }
+            task();
+        }
+    }
+};
+
+ThreadPool::ThreadPool() : m_impl(new Impl) {}
+ThreadPool::~ThreadPool()
+{
+    waitAllTasksDone();
+    delete m_impl;
+}
+void ThreadPool::create(int32_t threadCount)
+{
+    if (threadCount <= 0) {
+        int32_t n = (int32_t)std::thread::hardware_concurrency() + threadCount;
+        threadCount = n > 0 ? n : 8;
+    }
+    m_impl->alive = true;
+    for (int32_t i = 0; i < threadCount; i++) m_impl->workers.emplace_back([this] { m_impl->run(); });
+}
+void ThreadPool::queue(Task task)
+{
+    std::unique_lock<std::mutex> g(m_impl->mutex);
+    m_impl->tasks.push_back(std::move(task));
+    m_impl->cond.notify_one();
+}
+void ThreadPool::waitAllTasksDone()
+{
+    {
+        std::unique_lock<std::mutex> g(m_impl->mutex);
+        if (!m_impl->alive) return;
+        m_impl->alive = false;
+    }
+    m_impl->cond.notify_all();
+    for (auto& w : m_impl->workers) w.join();
+    m_impl->workers.clear();
+}
+size_t ThreadPool::getTaskCount() const
+{
+    std::unique_lock<std::mutex> g(m_impl->mutex);
+    return m_impl->tasks.size();
+}
+
+// ---------------------------------------------------------------- PathTracer -> C-ABI
+namespace
+{
+struct DeviceSlot {
+    prt_hip_ctx* ctx = nullptr;
+    const Scene* scene = nullptr;
+    uint64_t sceneRevision = 0;
+    prt_camera_desc camera{};
+    bool haveCamera = false;
+};
+std::mutex g_deviceMutex;
+std::map<int, DeviceSlot> g_devices;
+
+[[noreturn]] void die(const char* what)
+{
+    fprintf(stderr, "prt: %s: %s\n", what, prt_hip_last_error());
+    abort(); // the reference traps on failed assertions too (prt.h:7-13)
+}
+} // namespace
+
+void PathTracer::releaseDevice()
+{
+    std::lock_guard<std::mutex> g(g_deviceMutex);
+    for (auto& kv : g_devices) prt_hip_destroy(kv.second.ctx);
+    g_devices.clear();
+}
+
+void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const Scene& scene, const Camera& camera,
+                            uint32_t samples)
+{
+    std::lock_guard<std::mutex> g(g_deviceMutex); // calls on one context are serialised (prt_hip.h)
+    DeviceSlot& slot = g_devices[m_options.device];
+    if (!slot.ctx && prt_hip_create(m_options.device, &slot.ctx) != PRT_HIP_OK) die("prt_hip_create");
+    if (slot.scene != &scene || slot.sceneRevision != scene.getRevision()) {
+        prt_scene_desc desc;
+        Scene::DescStorage store;
+        scene.describe(desc, store);
+        if (prt_hip_upload_scene(slot.ctx, &desc) != PRT_HIP_OK) die("prt_hip_upload_scene");
+        slot.scene = &scene;
+        slot.sceneRevision = scene.getRevision();
+    }
+    prt_camera_desc cd;
+    camera.describe(cd);
+    if (!slot.haveCamera || memcmp(&cd, &slot.camera, sizeof(cd)) != 0) {
+        if (prt_hip_set_camera(slot.ctx, &cd) != PRT_HIP_OK) die("prt_hip_set_camera");
+        slot.camera = cd;
+        slot.haveCamera = true;
+    }
+    prt_render_params p{};
+    p.samples = samples;
+    p.maxDepth = m_options.maxDepth;
+    p.rrDepth = m_options.rrDepth;
+    p.seed = m_options.seed;
+    p.exposure = image.getExposure();
+    p.tileSize = 16; // main.cpp:123-124
+    p.rank = 0;
+    p.nranks = 1;
+    if (prt_hip_render(slot.ctx, x0, y0, x1, y1, &p, nullptr, nullptr) != PRT_HIP_OK) die("prt_hip_render");
+    if (prt_hip_download(slot.ctx, image.getPixels(), x0, y0, x1, y1) != PRT_HIP_OK) die("prt_hip_download");
+    prt_hip_stats st;
+    if (prt_hip_get_stats(slot.ctx, &st) != PRT_HIP_OK) die("prt_hip_get_stats");
+    m_stats.raysTraced += st.raysTraced;
+    m_stats.occludedTraced += st.occludedTraced;
+    m_kernelMs += st.kernelMs;
+}
+
+} // namespace prt

@@ -1,0 +1,552 @@
+// prt_models.cpp -- scene data producers: the Cornell box of the reference's default setup, an
+// OBJ reader (the reference delegates to tinyobjloader, which is not vendored), and seeded
+// procedural stand-ins for the assets its other setups load but does not ship.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "prt.h"
+
+namespace prt
+{
+
+#include "cornell_data.inc"
+
+static float fromBits(uint32_t u)
+{
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// sample_models.cpp:11-207: 72 vertices, 36 triangles, 18 materials (one per quad), light emissive (17,12,4)
+Mesh SampleModels::getCornellBox(bool box)
+{
+    Mesh mesh;
+    const uint32_t primCount = box ? kCornellPrimCount : 12; // without the boxes: 5 walls + light
+    const uint32_t matCount = box ? kCornellMaterialCount : 6;
+    mesh.create(primCount, kCornellVertexCount, matCount, false);
+    for (uint32_t i = 0; i < kCornellVertexCount; i++)
+        mesh.getPositionBuffer()[i] = Vector3f(fromBits(kCornellPositionBits[3 * i]), fromBits(kCornellPositionBits[3 * i + 1]),
+                                               fromBits(kCornellPositionBits[3 * i + 2]));
+    auto copyPrim = [&](uint32_t dst, uint32_t src, uint32_t mat) {
+        for (uint32_t j = 0; j < 3; j++) mesh.getIndexBuffer()[3 * dst + j] = kCornellIndices[3 * src + j];
+        mesh.getPrimMateialBuffer()[dst] = mat;
+    };
+    auto copyMat = [&](uint32_t dst, uint32_t src) {
+        Material& m = mesh.getMaterialBuffer()[dst];
+        m.init();
+        m.diffuse = Vector3f(fromBits(kCornellMaterials[src][0]), fromBits(kCornellMaterials[src][1]), fromBits(kCornellMaterials[src][2]));
+        m.emissive = Vector3f(fromBits(kCornellMaterials[src][3]), fromBits(kCornellMaterials[src][4]), fromBits(kCornellMaterials[src][5]));
+        m.reflectionType = (ReflectionType)kCornellMaterials[src][6];
+    };
+    if (box) {
+        for (uint32_t p = 0; p < primCount; p++) copyPrim(p, p, kCornellPrimMaterial[p]);
+        for (uint32_t m = 0; m < matCount; m++) copyMat(m, m);
+    } else {
+        for (uint32_t p = 0; p < 10; p++) copyPrim(p, p, kCornellPrimMaterial[p]);
+        copyPrim(10, kCornellPrimCount - 2, 5);
+        copyPrim(11, kCornellPrimCount - 1, 5);
+        for (uint32_t m = 0; m < 5; m++) copyMat(m, m);
+        copyMat(5, kCornellMaterialCount - 1);
+    }
+    mesh.calculateBounds();
+    return mesh;
+}
+
+// ---------------------------------------------------------------- OBJ
+namespace
+{
+struct ObjData {
+    std::vector<Vector3f> positions;
+    std::vector<Vector2f> texcoords; // per VERTEX, (u, 1-v), last writer wins (mesh.cpp:272-286)
+    std::vector<uint32_t> indices;
+    std::vector<int32_t> primMaterial;
+    std::vector<std::string> materialNames;
+    std::string mtllib;
+};
+
+bool parseObj(const char* path, ObjData& o)
+{
+    std::ifstream f(path);
+    if (!f.is_open()) return false;
+    std::vector<Vector2f> vt;
+    std::map<std::string, int32_t> matIndex;
+    int32_t curMat = -1;
+    std::string line;
+    struct Corner { int32_t v, t; };
+    std::vector<Corner> corners;
+    while (std::getline(f, line)) {
+        const char* s = line.c_str();
+        while (*s == ' ' || *s == '\t') s++;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            char* e;
+            double x = strtod(s + 2, &e), y = strtod(e, &e), z = strtod(e, &e);
+            o.positions.push_back(Vector3f((float)x, (float)y, (float)z));
+        } else if (s[0] == 'v' && s[1] == 't') {
+            char* e;
+            double u = strtod(s + 2, &e), v = strtod(e, &e);
+            vt.push_back(Vector2f((float)u, (float)v));
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            corners.clear();
+            const char* p = s + 1;
+            for (;;) {
+                while (*p == ' ' || *p == '\t') p++;
+                if (!*p || *p == '\r' || *p == '\n') break;
+                char* e;
+                long v = strtol(p, &e, 10);
+                if (e == p) break;
+                long t = 0;
+                bool hasT = false;
+                p = e;
+                if (*p == '/') {
+                    p++;
+                    if (*p != '/') {
+                        t = strtol(p, &e, 10);
+                        hasT = e != p;
+                        p = e;
+                    }
+                    if (*p == '/') {
+                        p++;
+                        (void)strtol(p, &e, 10);
+                        p = e;
+                    }
+                }
+                Corner c;
+                c.v = (int32_t)(v > 0 ? v - 1 : (long)o.positions.size() + v);
+                c.t = hasT ? (int32_t)(t > 0 ? t - 1 : (long)vt.size() + t) : -1;
+                corners.push_back(c);
+            }
+            // fan triangulation 0-(k)-(k+1)
+            for (size_t k = 1; k + 1 < corners.size(); k++) {
+                const Corner tri[3] = {corners[0], corners[k], corners[k + 1]};
+                for (const Corner& c : tri) {
+                    if (o.texcoords.size() < o.positions.size()) o.texcoords.resize(o.positions.size(), Vector2f(0.0f));
+                    if (c.v < 0 || (size_t)c.v >= o.positions.size()) return false;
+                    o.texcoords[c.v] = (c.t >= 0 && (size_t)c.t < vt.size()) ? Vector2f(vt[c.t].x, 1.0f - vt[c.t].y) : Vector2f(0.0f);
+                    o.indices.push_back((uint32_t)c.v);
+                }
+                o.primMaterial.push_back(curMat);
+            }
+        } else if (!strncmp(s, "usemtl", 6)) {
+            std::istringstream is(s + 6);
+            std::string name;
+            is >> name;
+            auto it = matIndex.find(name);
+            if (it == matIndex.end()) {
+                curMat = (int32_t)o.materialNames.size();
+                matIndex[name] = curMat;
+                o.materialNames.push_back(name);
+            } else {
+                curMat = it->second;
+            }
+        } else if (!strncmp(s, "mtllib", 6)) {
+            std::istringstream is(s + 6);
+            is >> o.mtllib;
+        }
+    }
+    o.texcoords.resize(o.positions.size(), Vector2f(0.0f));
+    return true;
+}
+
+// Binary PPM (P6, 3 components -> RGBA with alpha 255), PGM (P5) and PAM (P7 RGB_ALPHA) textures.
+bool loadPnm(const std::string& path, Texture& tex, bool bump)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    int w = 0, h = 0, maxv = 255, depth = 0;
+    if (fscanf(f, "%2s", magic) != 1) { fclose(f); return false; }
+    if (!strcmp(magic, "P7")) {
+        char key[64];
+        while (fscanf(f, "%63s", key) == 1) {
+            if (!strcmp(key, "WIDTH")) { if (fscanf(f, "%d", &w) != 1) break; }
+            else if (!strcmp(key, "HEIGHT")) { if (fscanf(f, "%d", &h) != 1) break; }
+            else if (!strcmp(key, "DEPTH")) { if (fscanf(f, "%d", &depth) != 1) break; }
+            else if (!strcmp(key, "MAXVAL")) { if (fscanf(f, "%d", &maxv) != 1) break; }
+            else if (!strcmp(key, "TUPLTYPE")) { if (fscanf(f, "%63s", key) != 1) break; }
+            else if (!strcmp(key, "ENDHDR")) break;
+        }
+    } else if (!strcmp(magic, "P6") || !strcmp(magic, "P5")) {
+        depth = magic[1] == '6' ? 3 : 1;
+        if (fscanf(f, "%d %d %d", &w, &h, &maxv) != 3) { fclose(f); return false; }
+    } else {
+        fclose(f);
+        return false;
+    }
+    fgetc(f);
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || maxv != 255 || depth < 1 || depth > 4) { fclose(f); return false; }
+    std::vector<uint8_t> raw((size_t)w * h * depth);
+    bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) return false;
+    // texture.cpp:226-247: grey stays 1 component, everything else becomes RGBA; 3-component bump maps become
+    // a 1-component height field (convertNormalToBump, texture.cpp:185-200)
+    if (depth == 1) {
+        tex.create((uint16_t)w, (uint16_t)h, 1, raw.data());
+        return true;
+    }
+    std::vector<uint8_t> rgba((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        rgba[4 * i + 0] = raw[depth * i + 0];
+        rgba[4 * i + 1] = depth >= 3 ? raw[depth * i + 1] : raw[depth * i];
+        rgba[4 * i + 2] = depth >= 3 ? raw[depth * i + 2] : raw[depth * i];
+        rgba[4 * i + 3] = depth == 4 ? raw[depth * i + 3] : (depth == 2 ? raw[depth * i + 1] : 255);
+    }
+    if (bump && depth == 3) {
+        std::vector<uint8_t> b((size_t)w * h);
+        const float kChannelScale = 1.0f / 255.0f;
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            float nx = 2.0f * (rgba[4 * i + 0] * kChannelScale - 0.5f);
+            float ny = 2.0f * (rgba[4 * i + 1] * kChannelScale - 0.5f);
+            float nz = 2.0f * (rgba[4 * i + 2] * kChannelScale - 0.5f);
+            auto n = normalize(Vector3f(nx, ny, nz));
+            float v = std::fmin(std::fmax(n.z * n.z * n.z * n.z, 0.0f), 1.0f);
+            b[i] = (uint8_t)(0xff * v);
+        }
+        tex.create((uint16_t)w, (uint16_t)h, 1, b.data());
+        return true;
+    }
+    tex.create((uint16_t)w, (uint16_t)h, 4, rgba.data());
+    return true;
+}
+
+void parseMtl(const std::string& path, const std::string& dir, const std::vector<std::string>& names, std::vector<Material>& mats)
+{
+    std::ifstream f(path);
+    if (!f.is_open()) return;
+    std::map<std::string, size_t> idx;
+    for (size_t i = 0; i < names.size(); i++) idx[names[i]] = i;
+    Material* cur = nullptr;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        std::string key;
+        is >> key;
+        if (key == "newmtl") {
+            std::string n;
+            is >> n;
+            auto it = idx.find(n);
+            cur = it == idx.end() ? nullptr : &mats[it->second];
+        } else if (cur && key == "Kd") {
+            is >> cur->diffuse.x >> cur->diffuse.y >> cur->diffuse.z;
+        } else if (cur && key == "Ke") {
+            is >> cur->emissive.x >> cur->emissive.y >> cur->emissive.z;
+        } else if (cur && key == "Ka") {
+            is >> cur->ambient.x >> cur->ambient.y >> cur->ambient.z;
+        } else if (cur && key == "Ks") {
+            is >> cur->specular.x >> cur->specular.y >> cur->specular.z;
+        } else if (cur && (key == "map_Kd" || key == "map_bump" || key == "bump" || key == "map_Bump")) {
+            std::string name, tok;
+            while (is >> tok) name = tok; // last token is the file name (options precede it)
+            for (auto& c : name)
+                if (c == '\\') c = '/';
+            bool bump = key != "map_Kd";
+            Texture& t = bump ? cur->bumpMap : cur->diffuseMap;
+            if (!loadPnm(dir + "/" + name, t, bump))
+                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM only: stb is not vendored)\n", name.c_str());
+        }
+    }
+    for (auto& m : mats) m.alphaTest = m.diffuseMap.isAlphaTestRequired(); // material.cpp:79
+}
+} // namespace
+
+void Mesh::loadObj(const char* path, const Material& mat) // mesh.cpp:151-209
+{
+    ObjData o;
+    if (!parseObj(path, o)) {
+        logPrintf(LogLevel::kError, "Failed to load %s\n", path);
+        return;
+    }
+    create((uint32_t)o.indices.size() / 3, (uint32_t)o.positions.size(), 1, false);
+    m_indices = o.indices;
+    m_positions = o.positions;
+    // The reference copies only the first vertexCount*4 BYTES of the raw vt list here (mesh.cpp:200) and leaves the
+    // rest of the buffer uninitialised; texcoords are never read for an untextured material, so the per-vertex
+    // (u, 1-v) table of the other overload is used instead.
+    m_texcoords = o.texcoords;
+    std::fill(m_primMaterial.begin(), m_primMaterial.end(), 0u);
+    m_materials[0] = mat;
+    calculateBounds();
+    m_hasTexcoord = true;
+    logPrintf(LogLevel::kVerbose, "Finished loading '%s'\n", path);
+}
+
+void Mesh::loadObj(const char* path) // mesh.cpp:211-300
+{
+    ObjData o;
+    if (!parseObj(path, o)) {
+        logPrintf(LogLevel::kError, "Failed to load %s\n", path);
+        return;
+    }
+    std::string p(path), dir = ".";
+    size_t slash = p.find_last_of("/\\");
+    if (slash != std::string::npos) dir = p.substr(0, slash);
+    size_t matCount = std::max<size_t>(o.materialNames.size(), 1);
+    create((uint32_t)o.indices.size() / 3, (uint32_t)o.positions.size(), (uint32_t)matCount, false);
+    m_indices = o.indices;
+    m_positions = o.positions;
+    m_texcoords = o.texcoords;
+    for (size_t i = 0; i < m_primMaterial.size(); i++) m_primMaterial[i] = o.primMaterial[i] < 0 ? 0u : (uint32_t)o.primMaterial[i];
+    if (!o.mtllib.empty()) parseMtl(dir + "/" + o.mtllib, dir, o.materialNames, m_materials);
+    calculateBounds();
+    m_hasTexcoord = true;
+    logPrintf(LogLevel::kVerbose, "Finished loading '%s' prim=%u, vtx=%u\n", path, getPrimCount(), getVertexCount());
+}
+
+// ---------------------------------------------------------------- procedural stand-ins
+namespace
+{
+struct Lcg { // fixed generator so that the stand-ins are identical on every box
+    uint64_t s;
+    explicit Lcg(uint64_t seed) : s(seed * 6364136223846793005ull + 1442695040888963407ull) {}
+    uint32_t next()
+    {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t)(s >> 33);
+    }
+    float uniform() { return (float)(next() & 0xffffff) / 16777216.0f; }
+    float range(float a, float b) { return a + (b - a) * uniform(); }
+};
+} // namespace
+
+// Bunny-class stand-in: a lat-long sphere of ~targetTris triangles whose radius is displaced by a
+// few octaves of seeded sinusoids.  2*segments*rings triangles.
+Mesh SampleModels::getDisplacedSphere(uint32_t targetTris, float radius, const Vector3f& center, const Material& mat, uint32_t seed)
+{
+    uint32_t rings = std::max(3u, (uint32_t)std::lround(std::sqrt((double)targetTris / 4.0)));
+    uint32_t segs = std::max(3u, (uint32_t)(targetTris / (2 * rings)));
+    Lcg rng(seed);
+    const int kWaves = 12;
+    float amp[kWaves], fx[kWaves], fy[kWaves], fz[kWaves], ph[kWaves];
+    for (int i = 0; i < kWaves; i++) {
+        float octave = (float)(1 + i / 3);
+        amp[i] = 0.12f / octave;
+        fx[i] = rng.range(-3.0f, 3.0f) * octave;
+        fy[i] = rng.range(-3.0f, 3.0f) * octave;
+        fz[i] = rng.range(-3.0f, 3.0f) * octave;
+        ph[i] = rng.range(0.0f, 6.2831853f);
+    }
+    auto displaced = [&](float theta, float phi) {
+        Vector3f d(std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi));
+        float r = 1.0f;
+        for (int i = 0; i < kWaves; i++) r += amp[i] * std::sin(fx[i] * d.x + fy[i] * d.y + fz[i] * d.z + ph[i]);
+        return center + (radius * r) * d;
+    };
+    const uint32_t vertexCount = 2 + (rings - 1) * segs;
+    const uint32_t primCount = 2 * segs + 2 * segs * (rings - 2);
+    Mesh mesh;
+    mesh.create(primCount, vertexCount, 1, false);
+    Vector3f* pos = mesh.getPositionBuffer();
+    Vector2f* tex = mesh.getTexcoordBuffer();
+    const float kPiF = 3.14159265358979323846f;
+    pos[0] = displaced(0.0f, 0.0f);
+    tex[0] = Vector2f(0.5f, 0.0f);
+    for (uint32_t r = 1; r < rings; r++)
+        for (uint32_t s = 0; s < segs; s++) {
+            float theta = kPiF * (float)r / (float)rings, phi = 2.0f * kPiF * (float)s / (float)segs;
+            pos[1 + (r - 1) * segs + s] = displaced(theta, phi);
+            tex[1 + (r - 1) * segs + s] = Vector2f((float)s / (float)segs, (float)r / (float)rings);
+        }
+    pos[vertexCount - 1] = displaced(kPiF, 0.0f);
+    tex[vertexCount - 1] = Vector2f(0.5f, 1.0f);
+    uint32_t* idx = mesh.getIndexBuffer();
+    uint32_t k = 0;
+    auto ring = [&](uint32_t r, uint32_t s) { return 1 + (r - 1) * segs + (s % segs); };
+    for (uint32_t s = 0; s < segs; s++) { idx[k++] = 0; idx[k++] = ring(1, s + 1); idx[k++] = ring(1, s); }
+    for (uint32_t r = 1; r + 1 < rings; r++)
+        for (uint32_t s = 0; s < segs; s++) {
+            idx[k++] = ring(r, s); idx[k++] = ring(r, s + 1); idx[k++] = ring(r + 1, s);
+            idx[k++] = ring(r, s + 1); idx[k++] = ring(r + 1, s + 1); idx[k++] = ring(r + 1, s);
+        }
+    for (uint32_t s = 0; s < segs; s++) { idx[k++] = vertexCount - 1; idx[k++] = ring(rings - 1, s); idx[k++] = ring(rings - 1, s + 1); }
+    mesh.getMaterialBuffer()[0] = mat;
+    mesh.setHasTexcoord(true);
+    mesh.calculateBounds();
+    return mesh;
+}
+
+// Sponza-class stand-in: a two-storey colonnaded hall ("atrium") -- floor, walls, an open roof
+// ring, two rows of faceted columns joined by arches, and hanging banners/foliage cards.  With alphaMasked the cards
+// (about a fifth of the triangles) carry a procedural RGBA leaf mask; with bumpMapped the floor carries a height map;
+// emissiveFraction turns that share of the card materials into emitters (Zero-Day-class stand-in).
+Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMasked, bool bumpMapped, float emissiveFraction)
+{
+    Lcg rng(seed);
+    std::vector<Vector3f> P;
+    std::vector<Vector2f> T;
+    std::vector<uint32_t> I, PM;
+    auto vert = [&](const Vector3f& p, const Vector2f& t) { P.push_back(p); T.push_back(t); return (uint32_t)P.size() - 1; };
+    auto tri = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t m) { I.push_back(a); I.push_back(b); I.push_back(c); PM.push_back(m); };
+    // a grid patch from origin o spanning du, dv with nu x nv cells (winding so that cross(du,dv) is the normal)
+    auto patch = [&](const Vector3f& o, const Vector3f& du, const Vector3f& dv, uint32_t nu, uint32_t nv, uint32_t m, float uvScale) {
+        uint32_t base = (uint32_t)P.size();
+        for (uint32_t j = 0; j <= nv; j++)
+            for (uint32_t i = 0; i <= nu; i++) {
+                float a = (float)i / (float)nu, b = (float)j / (float)nv;
+                vert(o + a * du + b * dv, Vector2f(a * uvScale, b * uvScale));
+            }
+        for (uint32_t j = 0; j < nv; j++)
+            for (uint32_t i = 0; i < nu; i++) {
+                uint32_t v0 = base + j * (nu + 1) + i, v1 = v0 + 1, v2 = v0 + nu + 1, v3 = v2 + 1;
+                tri(v0, v1, v2, m);
+                tri(v1, v3, v2, m);
+            }
+    };
+    enum { kFloor = 0, kWall, kColumn, kArch, kRoof, kCardFirst };
+    const uint32_t kCardMaterials = 8;
+    // budget: 30% shell, 50% columns+arches, 20% cards
+    const float L = 36.0f, W = 14.0f, H = 12.0f;
+    uint32_t shellCells = std::max(2u, (uint32_t)std::sqrt((double)targetTris * 0.30 / (2.0 * 5.2)));
+    uint32_t nL = shellCells * 2, nW = shellCells, nH = shellCells;
+    patch(Vector3f(-L / 2, 0, W / 2), Vector3f(L, 0, 0), Vector3f(0, 0, -W), nL, nW, kFloor, 8.0f);            // floor (+y)
+    patch(Vector3f(-L / 2, 0, -W / 2), Vector3f(L, 0, 0), Vector3f(0, H, 0), nL, nH, kWall, 4.0f);             // back wall (+z)
+    patch(Vector3f(L / 2, 0, W / 2), Vector3f(-L, 0, 0), Vector3f(0, H, 0), nL, nH, kWall, 4.0f);              // front wall (-z)
+    patch(Vector3f(-L / 2, 0, W / 2), Vector3f(0, 0, -W), Vector3f(0, H, 0), nW, nH, kWall, 4.0f);             // left wall (+x)
+    patch(Vector3f(L / 2, 0, -W / 2), Vector3f(0, 0, W), Vector3f(0, H, 0), nW, nH, kWall, 4.0f);              // right wall (-x)
+    // roof ring: two strips along the long walls leave the middle open to the sky light
+    patch(Vector3f(-L / 2, H, -W / 2), Vector3f(L, 0, 0), Vector3f(0, 0, W * 0.3f), nL, std::max(1u, nW / 3), kRoof, 4.0f);
+    patch(Vector3f(-L / 2, H, W * 0.2f), Vector3f(L, 0, 0), Vector3f(0, 0, W * 0.3f), nL, std::max(1u, nW / 3), kRoof, 4.0f);
+    // columns: two rows of 10, faceted cylinders with entasis; arches between neighbours
+    const uint32_t colCount = 20;
+    uint32_t colTris = (uint32_t)((double)targetTris * 0.36 / colCount);
+    uint32_t cs = std::max(6u, (uint32_t)std::sqrt((double)colTris / 2.0 * 0.5)), ch = std::max(2u, colTris / (2 * cs));
+    const float kPiF = 3.14159265358979323846f;
+    for (uint32_t c = 0; c < colCount; c++) {
+        float cx = -L / 2 + L * ((float)(c % 10) + 0.5f) / 10.0f, cz = (c < 10) ? -W * 0.28f : W * 0.28f;
+        uint32_t base = (uint32_t)P.size();
+        for (uint32_t j = 0; j <= ch; j++)
+            for (uint32_t i = 0; i <= cs; i++) {
+                float a = 2.0f * kPiF * (float)i / (float)cs, y = 7.0f * (float)j / (float)ch;
+                float r = 0.45f * (1.0f - 0.15f * (float)j / (float)ch) + 0.03f * std::sin(8.0f * a);
+                vert(Vector3f(cx + r * std::cos(a), y, cz + r * std::sin(a)), Vector2f((float)i / (float)cs * 2.0f, y));
+            }
+        for (uint32_t j = 0; j < ch; j++)
+            for (uint32_t i = 0; i < cs; i++) {
+                uint32_t v0 = base + j * (cs + 1) + i, v1 = v0 + 1, v2 = v0 + cs + 1, v3 = v2 + 1;
+                tri(v0, v2, v1, kColumn);
+                tri(v1, v2, v3, kColumn);
+            }
+    }
+    uint32_t archTris = (uint32_t)((double)targetTris * 0.14 / 18.0);
+    uint32_t as = std::max(4u, archTris / 8);
+    for (uint32_t c = 0; c < colCount; c++) {
+        if (c % 10 == 9) continue;
+        float x0 = -L / 2 + L * ((float)(c % 10) + 0.5f) / 10.0f, x1 = x0 + L / 10.0f, cz = (c < 10) ? -W * 0.28f : W * 0.28f;
+        float xc = 0.5f * (x0 + x1), rad = 0.5f * (x1 - x0);
+        // a band following a semicircle from (x0,7) to (x1,7), with thickness in z and a flat top at y = 9.5
+        for (int side = 0; side < 2; side++) {
+            float z = cz + (side ? 0.35f : -0.35f);
+            uint32_t base = (uint32_t)P.size();
+            for (uint32_t i = 0; i <= as; i++) {
+                float a = kPiF * (float)i / (float)as;
+                float ax = xc - rad * std::cos(a), ay = 7.0f + rad * 0.9f * std::sin(a);
+                vert(Vector3f(ax, ay, z), Vector2f((float)i / (float)as, 0.0f));
+                vert(Vector3f(ax, 9.5f, z), Vector2f((float)i / (float)as, 1.0f));
+            }
+            for (uint32_t i = 0; i < as; i++) {
+                uint32_t v0 = base + 2 * i, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;
+                if (side) { tri(v0, v2, v1, kArch); tri(v1, v2, v3, kArch); }
+                else { tri(v0, v1, v2, kArch); tri(v1, v3, v2, kArch); }
+            }
+        }
+        // underside of the arch
+        uint32_t base = (uint32_t)P.size();
+        for (uint32_t i = 0; i <= as; i++) {
+            float a = kPiF * (float)i / (float)as;
+            float ax = xc - rad * std::cos(a), ay = 7.0f + rad * 0.9f * std::sin(a);
+            vert(Vector3f(ax, ay, cz - 0.35f), Vector2f((float)i / (float)as, 0.0f));
+            vert(Vector3f(ax, ay, cz + 0.35f), Vector2f((float)i / (float)as, 1.0f));
+        }
+        for (uint32_t i = 0; i < as; i++) {
+            uint32_t v0 = base + 2 * i, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3;
+            tri(v0, v2, v1, kArch);
+            tri(v1, v2, v3, kArch);
+        }
+    }
+    // cards: small randomly oriented quads (2 triangles each), clustered like foliage / banners
+    uint32_t have = (uint32_t)I.size() / 3;
+    uint32_t cardTris = targetTris > have ? targetTris - have : 0;
+    uint32_t cards = cardTris / 2;
+    for (uint32_t c = 0; c < cards; c++) {
+        Vector3f centre(rng.range(-L / 2 + 1, L / 2 - 1), rng.range(0.3f, H - 1.0f), rng.range(-W / 2 + 0.5f, W / 2 - 0.5f));
+        float a = rng.range(0.0f, 2.0f * kPiF), tilt = rng.range(-0.6f, 0.6f), sz = rng.range(0.08f, 0.35f);
+        Vector3f u(std::cos(a) * sz, std::sin(tilt) * sz, std::sin(a) * sz);
+        Vector3f v(-std::sin(a) * std::sin(tilt) * sz, std::cos(tilt) * sz, std::cos(a) * std::sin(tilt) * sz);
+        uint32_t m = kCardFirst + (rng.next() % kCardMaterials);
+        uint32_t v0 = vert(centre - u - v, Vector2f(0, 0)), v1 = vert(centre + u - v, Vector2f(1, 0));
+        uint32_t v2 = vert(centre - u + v, Vector2f(0, 1)), v3 = vert(centre + u + v, Vector2f(1, 1));
+        tri(v0, v1, v2, m);
+        tri(v1, v3, v2, m);
+    }
+
+    Mesh mesh;
+    mesh.create((uint32_t)I.size() / 3, (uint32_t)P.size(), kCardFirst + kCardMaterials, false);
+    memcpy(mesh.getIndexBuffer(), I.data(), I.size() * 4);
+    memcpy((void*)mesh.getPositionBuffer(), P.data(), P.size() * sizeof(Vector3f));
+    memcpy((void*)mesh.getTexcoordBuffer(), T.data(), T.size() * sizeof(Vector2f));
+    memcpy(mesh.getPrimMateialBuffer(), PM.data(), PM.size() * 4);
+    mesh.setHasTexcoord(true);
+    Material* mats = mesh.getMaterialBuffer();
+    const Vector3f stone(0.62f, 0.58f, 0.5f);
+    mats[kFloor].diffuse = Vector3f(0.55f, 0.5f, 0.45f);
+    mats[kWall].diffuse = stone;
+    mats[kColumn].diffuse = Vector3f(0.7f, 0.68f, 0.62f);
+    mats[kArch].diffuse = stone;
+    mats[kRoof].diffuse = Vector3f(0.4f, 0.38f, 0.36f);
+    Texture leaf, height;
+    if (alphaMasked) {
+        const uint32_t S = 256;
+        std::vector<uint8_t> px((size_t)S * S * 4);
+        Lcg tr(seed ^ 0x51ed27u);
+        // blobs: alpha 255 inside a few random discs, 0 elsewhere, soft edge
+        float bx[24], by[24], br[24];
+        for (int i = 0; i < 24; i++) { bx[i] = tr.uniform(); by[i] = tr.uniform(); br[i] = tr.range(0.06f, 0.2f); }
+        for (uint32_t y = 0; y < S; y++)
+            for (uint32_t x = 0; x < S; x++) {
+                float fx = ((float)x + 0.5f) / S, fy = ((float)y + 0.5f) / S, a = 0.0f;
+                for (int i = 0; i < 24; i++) {
+                    float dx = fx - bx[i], dy = fy - by[i];
+                    float d = std::sqrt(dx * dx + dy * dy) / br[i];
+                    a = std::fmax(a, std::fmin(std::fmax((1.0f - d) * 6.0f, 0.0f), 1.0f));
+                }
+                uint8_t* p = &px[((size_t)y * S + x) * 4];
+                p[0] = (uint8_t)(40 + (tr.next() & 31));
+                p[1] = (uint8_t)(120 + (tr.next() & 63));
+                p[2] = (uint8_t)(30 + (tr.next() & 31));
+                p[3] = (uint8_t)(255.0f * a);
+            }
+        leaf.create(S, S, 4, px.data());
+    }
+    if (bumpMapped) {
+        const uint32_t S = 256;
+        std::vector<uint8_t> px((size_t)S * S);
+        for (uint32_t y = 0; y < S; y++)
+            for (uint32_t x = 0; x < S; x++) {
+                // paving stones: raised tiles with grooves
+                float fx = (float)(x % 64) / 64.0f, fy = (float)(y % 64) / 64.0f;
+                float e = std::fmin(std::fmin(fx, 1.0f - fx), std::fmin(fy, 1.0f - fy));
+                px[(size_t)y * S + x] = (uint8_t)(255.0f * std::fmin(e * 8.0f, 1.0f));
+            }
+        height.create(S, S, 1, px.data());
+        mats[kFloor].bumpMap = height;
+    }
+    Lcg mr(seed ^ 0xabcdefu);
+    for (uint32_t k = 0; k < kCardMaterials; k++) {
+        Material& m = mats[kCardFirst + k];
+        m.diffuse = Vector3f(mr.range(0.3f, 0.9f), mr.range(0.3f, 0.9f), mr.range(0.3f, 0.9f));
+        if (alphaMasked) {
+            m.diffuseMap = leaf;
+            m.alphaTest = leaf.isAlphaTestRequired();
+        }
+        if ((float)k < emissiveFraction * (float)kCardMaterials) m.emissive = Vector3f(mr.range(2.0f, 9.0f), mr.range(2.0f, 9.0f), mr.range(1.0f, 6.0f));
+    }
+    mesh.calculateBounds();
+    return mesh;
+}
+
+} // namespace prt

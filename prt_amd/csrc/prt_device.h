@@ -1,0 +1,552 @@
+// prt_device.h -- per-ray device functions of the path: box tests, watertight triangle test,
+// the four BVH traversals, surface fetch and material sampling.  gfx950 only.
+//
+// Arithmetic contract: every expression below is the reference's expression in the reference's
+// order, evaluated in IEEE binary32 with no contraction (the file is compiled -ffp-contract=off,
+// no fast-math, correctly-rounded / and sqrt).  SSE min/max (second operand on NaN) are written
+// as selects, never fminf/fmaxf.  Reference citations are file:line under /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "prt_devmath.h"
+
+#define PRT_MAX_BVH 8
+#define PRT_STACK_LDS 24     // stack entries per lane kept in LDS
+#define PRT_STACK_MAX 64     // bvh.cpp:432,579
+#define PRT_BLOCK 256
+
+// ---------------------------------------------------------------------------- device scene
+// nodes:  2 x float4 per node  {lo.x lo.y lo.z hi.x} {hi.y hi.z a b}
+//         internal: a = index of the second child, b = 0x80000000 | splitAxis   (first child = i + 1)
+//         leaf:     a = first triangle record,     b = primCount
+// tris:   3 x float4 per triangle in primRemapping order {p0 primId} {p1 alphaRef} {p2 0}
+//         alphaRef = 0, or 1 + index of the alpha record
+// shade:  4 x float4 per triangle in MESH order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
+//         (n0 = precomputed face normal when the mesh has no vertex normals)
+// bump:   3 x float4 per triangle in mesh order {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
+// mats:   3 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0}
+// alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
+struct DevScene {
+    const float4* nodes;
+    const float4* tris;
+    const float4* shade;
+    const float4* bump;
+    const float4* mats;
+    const float4* alpha;
+    const uint4* texDesc; // {byte offset, width, height, component}
+    const uint8_t* texels;
+    uint32_t bvhCount;
+    uint32_t root[PRT_MAX_BVH];
+    uint32_t primBase[PRT_MAX_BVH];
+    uint32_t hasNormals[PRT_MAX_BVH];
+    uint32_t hasLight;
+    float lightDir[3];
+    float lightIntensity[3];
+    float radius;
+};
+
+struct DevCamera {
+    float pos[3], dir[3], up[3], right[3];
+    uint32_t width, height;
+    float invWidth, invHeight;
+};
+
+struct Vec3 {
+    float x, y, z;
+};
+struct Vec2 {
+    float x, y;
+};
+
+__device__ __forceinline__ Vec3 mk3(float x, float y, float z) { return Vec3{x, y, z}; }
+__device__ __forceinline__ Vec3 add3(Vec3 a, Vec3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ Vec3 sub3(Vec3 a, Vec3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ Vec3 mul3(Vec3 a, Vec3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ Vec3 div3s(Vec3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ Vec3 scale3(float f, Vec3 v) { return mk3(f * v.x, f * v.y, f * v.z); }
+__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vecmath.h:1181
+__device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float length3(Vec3 v) { return __fsqrt_rn(dot3(v, v)); }
+__device__ __forceinline__ Vec3 normalize3(Vec3 v) // vecmath.h:1200
+{
+    float invlen = 1.0f / length3(v);
+    return scale3(invlen, v);
+}
+__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
+
+struct DevRay {
+    Vec3 org, dir, inv;
+    bool swapXZ, swapYZ;
+};
+
+struct DevHit {
+    float t, i, j, k;
+    uint32_t primId, meshId;
+};
+
+struct Traffic {
+    uint32_t nBox, nTri, nHit, nTap;
+};
+
+// ray.h:26-40: swap axis from the SIGNED components (Vector3f::GetLongestElement, vecmath.h:216)
+__device__ __forceinline__ void prepare_single(DevRay& r)
+{
+    r.inv = mk3(1.0f / r.dir.x, 1.0f / r.dir.y, 1.0f / r.dir.z);
+    uint32_t e;
+    if (r.dir.x > r.dir.y) e = (r.dir.x > r.dir.z) ? 0u : 2u;
+    else e = (r.dir.y > r.dir.z) ? 1u : 2u;
+    r.swapXZ = (e == 0u);
+    r.swapYZ = (e == 1u);
+}
+
+// ray.h:58-71: largest |component|, x wins ties, then y
+__device__ __forceinline__ void prepare_soa(DevRay& r)
+{
+    r.inv = mk3(1.0f / r.dir.x, 1.0f / r.dir.y, 1.0f / r.dir.z);
+    float ax = fabsf(r.dir.x), ay = fabsf(r.dir.y), az = fabsf(r.dir.z);
+    float max_e = sse_max(ax, sse_max(ay, az));
+    bool mx = (max_e == ax);
+    r.swapXZ = mx;
+    r.swapYZ = (max_e == ay) && !mx;
+}
+
+// ---------------------------------------------------------------------------- box tests
+struct Box {
+    Vec3 lo, hi;
+};
+
+__device__ __forceinline__ void slabs(const Box& b, const DevRay& r, float t0[3], float t1[3])
+{
+    float a, c;
+    a = (b.lo.x - r.org.x) * r.inv.x; c = (b.hi.x - r.org.x) * r.inv.x; t0[0] = sse_min(a, c); t1[0] = sse_max(a, c);
+    a = (b.lo.y - r.org.y) * r.inv.y; c = (b.hi.y - r.org.y) * r.inv.y; t0[1] = sse_min(a, c); t1[1] = sse_max(a, c);
+    a = (b.lo.z - r.org.z) * r.inv.z; c = (b.hi.z - r.org.z) * r.inv.z; t0[2] = sse_min(a, c); t1[2] = sse_max(a, c);
+}
+
+// vecmath.h:1402-1424.  4th SSE lane: t0 = -inf, t1 = +inf; reductions op(op(a0,a2),op(a1,a3)) (:1325-1345)
+__device__ __forceinline__ float box_t(const Box& b, const DevRay& r)
+{
+    float t0[3], t1[3];
+    slabs(b, r, t0, t1);
+    const float inf = __builtin_inff();
+    float max_t0 = sse_max(sse_max(t0[0], t0[2]), sse_max(t0[1], -inf));
+    float min_t1 = sse_min(sse_min(t1[0], t1[2]), sse_min(t1[1], inf));
+    return (min_t1 < max_t0) ? inf : max_t0;
+}
+
+// vecmath.h:1449-1466.  4th lane: t0 = min(-FLT_MAX, maxT), t1 = max(-FLT_MAX, maxT)
+__device__ __forceinline__ bool box_bool(const Box& b, const DevRay& r, float maxT)
+{
+    float t0[3], t1[3];
+    slabs(b, r, t0, t1);
+    const float lowest = -3.402823466e+38f;
+    float w0 = sse_min(lowest, maxT), w1 = sse_max(lowest, maxT);
+    float max_t0 = sse_max(sse_max(t0[0], t0[2]), sse_max(t0[1], w0));
+    float min_t1 = sse_min(sse_min(t1[0], t1[2]), sse_min(t1[1], w1));
+    return min_t1 > max_t0;
+}
+
+// vecmath.h:1504-1518, one lane
+__device__ __forceinline__ bool box_soa(const Box& b, const DevRay& r, float maxT)
+{
+    float t0[3], t1[3];
+    slabs(b, r, t0, t1);
+    float max_t0 = sse_max(t0[0], sse_max(t0[1], t0[2]));
+    float min_t1 = sse_min(t1[0], sse_min(t1[1], t1[2]));
+    return (max_t0 < maxT) && (min_t1 >= max_t0);
+}
+
+// ---------------------------------------------------------------------------- triangle
+// triangle.cpp:90-166, one lane.  Returns t, or -1 (kNoIntersection).
+__device__ __forceinline__ float tri_intersect(const DevRay& r, Vec3 p0, Vec3 p1, Vec3 p2, float& bi, float& bj, float& bk)
+{
+    Vec3 d = r.dir;
+    Vec3 v0 = sub3(p0, r.org), v1 = sub3(p1, r.org), v2 = sub3(p2, r.org);
+    if (r.swapXZ) {
+        float t;
+        t = d.x; d.x = d.z; d.z = t;
+        t = v0.x; v0.x = v0.z; v0.z = t;
+        t = v1.x; v1.x = v1.z; v1.z = t;
+        t = v2.x; v2.x = v2.z; v2.z = t;
+    }
+    if (r.swapYZ) {
+        float t;
+        t = d.y; d.y = d.z; d.z = t;
+        t = v0.y; v0.y = v0.z; v0.z = t;
+        t = v1.y; v1.y = v1.z; v1.z = t;
+        t = v2.y; v2.y = v2.z; v2.z = t;
+    }
+    float v0z = v0.z, v1z = v1.z, v2z = v2.z;
+    float inv_dz = 1.0f / d.z;
+    float idx = d.x * inv_dz, idy = d.y * inv_dz; // invDzD, :119
+    float v0x = v0.x - idx * v0z, v0y = v0.y - idy * v0z;
+    float v1x = v1.x - idx * v1z, v1y = v1.y - idy * v1z;
+    float v2x = v2.x - idx * v2z, v2y = v2.y - idy * v2z;
+    float e0 = v1x * v2y - v1y * v2x;
+    float e1 = v2x * v0y - v2y * v0x;
+    float e2 = v0x * v1y - v0y * v1x;
+    bool mask_eb = (e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f);
+    bi = bj = bk = 0.0f;
+    if (mask_eb) return -1.0f;
+    float det = e0 + e1 + e2;
+    bool mask = (det < 0.0f) || (det > 0.0f); // _CMP_NEQ_OQ
+    float inv_det = 1.0f / det;
+    float t_scaled = (e0 * v0z + e1 * v1z + e2 * v2z) * inv_dz;
+    float t = t_scaled * inv_det;
+    mask = mask && (t > 0.0001f);
+    bi = e0 * inv_det;
+    bj = e1 * inv_det;
+    bk = e2 * inv_det;
+    return mask ? t : -1.0f;
+}
+
+// ---------------------------------------------------------------------------- textures (texture.cpp:31-183)
+__device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t component, Vec2 uv, int32_t width, int32_t height, bool soa)
+{
+    float s = uv.x - floorf(uv.x);
+    float t = uv.y - floorf(uv.y);
+    float xt, yt;
+    if (soa) {
+        xt = sse_max(s * (float)width - 0.5f, 0.0f);
+        yt = sse_max(t * (float)height - 0.5f, 0.0f);
+    } else {
+        xt = std_max(s * (float)width - 0.5f, 0.0f);
+        yt = std_max(t * (float)height - 0.5f, 0.0f);
+    }
+    int32_t x0 = (int32_t)floorf(xt), y0 = (int32_t)floorf(yt);
+    int32_t x1 = (x0 + 1 < width - 1) ? x0 + 1 : width - 1;
+    int32_t y1 = (y0 + 1 < height - 1) ? y0 + 1 : height - 1;
+    idx[0] = component * (x0 + y0 * width);
+    idx[1] = component * (x1 + y0 * width);
+    idx[2] = component * (x0 + y1 * width);
+    idx[3] = component * (x1 + y1 * width);
+    s = xt - (float)x0;
+    t = yt - (float)y0;
+    k[0] = (1.0f - s) * (1.0f - t);
+    k[1] = s * (1.0f - t);
+    k[2] = (1.0f - s) * t;
+    k[3] = s * t;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint32_t tex, Vec2 uv, bool soa, Traffic& tr)
+{
+    uint4 d = sc.texDesc[tex];
+    const uint8_t* p = sc.texels + d.x;
+    float k[4];
+    int32_t idx[4];
+    bilinear(k, idx, (int32_t)d.w, uv, (int32_t)d.y, (int32_t)d.z, soa);
+    if (COUNT) tr.nTap++;
+    float alpha = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) alpha = alpha + k[i] * (float)p[idx[i] + 3];
+    return alpha > 127.0f;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Vec3 tex_sample3(const DevScene& sc, uint32_t tex, Vec2 uv, Traffic& tr)
+{
+    uint4 d = sc.texDesc[tex];
+    const uint8_t* p = sc.texels + d.x;
+    float k[4];
+    int32_t idx[4];
+    bilinear(k, idx, (int32_t)d.w, uv, (int32_t)d.y, (int32_t)d.z, false);
+    if (COUNT) tr.nTap++;
+    Vec3 c = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint8_t* q = p + idx[i];
+        c = add3(c, scale3(k[i], mk3((float)q[0], (float)q[1], (float)q[2])));
+    }
+    return scale3(1.0f / 255.0f, c);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, Vec2 uv, Traffic& tr)
+{
+    uint4 d = sc.texDesc[tex];
+    const uint8_t* p = sc.texels + d.x;
+    float k[4];
+    int32_t idx[4];
+    bilinear(k, idx, (int32_t)d.w, uv, (int32_t)d.y, (int32_t)d.z, false);
+    if (COUNT) tr.nTap++;
+    float c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c = c + k[i] * (float)p[idx[i]];
+    return (1.0f / 255.0f) * c;
+}
+
+// ---------------------------------------------------------------------------- traversal stack
+// Entries 0..PRT_STACK_LDS-1 of a lane live in LDS ([entry][thread]: conflict-free for any mix of
+// depths), deeper ones in a per-thread global spill area ([entry][thread] as well).
+struct Stack {
+    uint32_t* lds;    // &ldsStack[threadIdx.x]
+    uint32_t* spill;  // &spill[globalThread]
+    uint32_t spillStride;
+    __device__ __forceinline__ void put(int e, uint32_t v) const
+    {
+        if (e < PRT_STACK_LDS) lds[e * PRT_BLOCK] = v;
+        else spill[(size_t)(e - PRT_STACK_LDS) * spillStride] = v;
+    }
+    __device__ __forceinline__ uint32_t get(int e) const
+    {
+        return (e < PRT_STACK_LDS) ? lds[e * PRT_BLOCK] : spill[(size_t)(e - PRT_STACK_LDS) * spillStride];
+    }
+};
+
+__device__ __forceinline__ void load_node(const DevScene& sc, uint32_t idx, Box& b, uint32_t& a, uint32_t& f)
+{
+    float4 n0 = sc.nodes[2 * (size_t)idx], n1 = sc.nodes[2 * (size_t)idx + 1];
+    b.lo = mk3(n0.x, n0.y, n0.z);
+    b.hi = mk3(n0.w, n1.x, n1.y);
+    a = asu(n1.z);
+    f = asu(n1.w);
+}
+
+#define PRT_NODE_INTERNAL 0x80000000u
+
+// bvh.cpp:302-368 (kNearest / kOcclude).  Returns true when occluded (OCCLUDE only).
+template <bool OCCLUDE, bool PACKET, bool COUNT>
+__device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t triStart, uint32_t primCount, uint32_t meshId,
+                                               const DevRay& r, float maxT, DevHit& hit, Traffic& tr)
+{
+    if (COUNT) tr.nTri += primCount;
+    // single: candidates need t < maxT with maxT = hit.t at leaf entry, nearest by strict <  (bvh.cpp:323,344)
+    // packet: t < hit.t, updated as the loop goes (bvh.cpp:392) -- the same running minimum
+    float best = maxT;
+    for (uint32_t i = 0; i < primCount; i++) {
+        const float4* tp = sc.tris + 3 * (size_t)(triStart + i);
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        float bi, bj, bk;
+        float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
+        if (!(t >= 0.0001f && t < best)) continue;
+        uint32_t alphaRef = asu(b.w);
+        if (alphaRef) {
+            const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
+            float4 u0 = ap[0], u1 = ap[1];
+            // i*uv0 + j*uv1 + k*uv2 (bvh.cpp:336, 407)
+            Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y};
+            if (!tex_test_alpha<COUNT>(sc, asu(u1.z), uv, PACKET, tr)) continue;
+        }
+        if (OCCLUDE) return true;
+        best = t;
+        hit.t = t;
+        hit.i = bi;
+        hit.j = bj;
+        hit.k = bk;
+        hit.primId = asu(a.w);
+        hit.meshId = meshId;
+    }
+    return false;
+}
+
+// Scene::intersect<SingleRayHitPacket,SingleRayPacket> (scene.cpp:47-63) over Bvh::intersect single branch
+// (bvh.cpp:429-570, SORT_CHILDREN): root bool test, both children tested per internal node, near child on top.
+template <bool COUNT>
+__device__ __forceinline__ void intersect_single(const DevScene& sc, const DevRay& r, float maxT, DevHit& hit, const Stack& st,
+                                                 Traffic& tr, uint32_t& overflow)
+{
+    hit.t = maxT;
+    hit.i = hit.j = hit.k = 0.0f;
+    hit.primId = 0;
+    hit.meshId = 0;
+    for (uint32_t m = 0; m < sc.bvhCount; m++) {
+        uint32_t cur = sc.root[m];
+        Box nb;
+        uint32_t na, nf;
+        load_node(sc, cur, nb, na, nf);
+        if (COUNT) tr.nBox++;
+        if (!box_bool(nb, r, hit.t)) continue;
+        int sp = 0; // number of entries below the node held in `cur`
+        for (;;) {
+            if (nf & PRT_NODE_INTERNAL) {
+                uint32_t c0 = cur + 1, c1 = na;
+                Box b0, b1;
+                uint32_t a0, f0, a1, f1;
+                load_node(sc, c0, b0, a0, f0);
+                load_node(sc, c1, b1, a1, f1);
+                if (COUNT) tr.nBox += 2;
+                float t0 = box_t(b0, r), t1 = box_t(b1, r);
+                bool h0 = t0 < hit.t, h1 = t1 < hit.t;
+                if (h0 && h1) {
+                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
+                    if (t0 < t1) { st.put(sp++, c1); cur = c0; nb = b0; na = a0; nf = f0; }
+                    else { st.put(sp++, c0); cur = c1; nb = b1; na = a1; nf = f1; }
+                    continue;
+                } else if (h0) {
+                    cur = c0; na = a0; nf = f0;
+                    continue;
+                } else if (h1) {
+                    cur = c1; na = a1; nf = f1;
+                    continue;
+                }
+            } else {
+                leaf_intersect<false, false, COUNT>(sc, na, nf, m, r, hit.t, hit, tr);
+            }
+            if (sp == 0) break;
+            cur = st.get(--sp);
+            load_node(sc, cur, nb, na, nf);
+        }
+    }
+    if (hit.t == maxT) hit.t = -1.0f;
+}
+
+// Scene::intersect<RayHitPacket,RayPacket> for ONE lane of the packet.  The reference walks the 8 rays
+// together with a per-entry lane mask (bvh.cpp:463-569); every mask update and hit update is lane-wise and
+// the visit order depends only on sign(avgDir[splitAxis]) (:523-529), so a lane walking alone over the nodes
+// where its own mask bit is set sees the same nodes in the same order with the same hit.t.
+template <bool COUNT>
+__device__ __forceinline__ void intersect_packet(const DevScene& sc, const DevRay& r, uint32_t reverseBits, float maxT, DevHit& hit,
+                                                 const Stack& st, Traffic& tr, uint32_t& overflow)
+{
+    hit.t = maxT;
+    hit.i = hit.j = hit.k = 0.0f;
+    hit.primId = 0;
+    hit.meshId = 0;
+    for (uint32_t m = 0; m < sc.bvhCount; m++) {
+        uint32_t cur = sc.root[m];
+        int sp = 0;
+        for (;;) {
+            Box nb;
+            uint32_t na, nf;
+            load_node(sc, cur, nb, na, nf);
+            if (COUNT) tr.nBox++;
+            if (box_soa(nb, r, hit.t)) {
+                if (nf & PRT_NODE_INTERNAL) {
+                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
+                    // popped first = top of stack: second child unless reverse (bvh.cpp:523-529)
+                    bool rev = (reverseBits >> (nf & 3u)) & 1u;
+                    uint32_t first = rev ? na : cur + 1, later = rev ? cur + 1 : na;
+                    st.put(sp++, later);
+                    cur = first;
+                    continue;
+                }
+                leaf_intersect<false, true, COUNT>(sc, na, nf, m, r, hit.t, hit, tr);
+            }
+            if (sp == 0) break;
+            cur = st.get(--sp);
+        }
+    }
+    if (hit.t == maxT) hit.t = -1.0f;
+}
+
+// Scene::occluded (scene.cpp:69-94) over Bvh::occluded (bvh.cpp:576-654); PACKET selects the SoA box test
+// (vecmath.h:1504) and per-lane semantics of the packet version, else the scalar bool test (:1449).
+// Fixed order: first child (i+1) popped first.
+template <bool PACKET, bool COUNT>
+__device__ __forceinline__ bool occluded(const DevScene& sc, const DevRay& r, float maxT, const Stack& st, Traffic& tr, uint32_t& overflow)
+{
+    DevHit dummy;
+    for (uint32_t m = 0; m < sc.bvhCount; m++) {
+        uint32_t cur = sc.root[m];
+        int sp = 0;
+        for (;;) {
+            Box nb;
+            uint32_t na, nf;
+            load_node(sc, cur, nb, na, nf);
+            if (COUNT) tr.nBox++;
+            bool h = PACKET ? box_soa(nb, r, maxT) : box_bool(nb, r, maxT);
+            if (h) {
+                if (nf & PRT_NODE_INTERNAL) {
+                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
+                    st.put(sp++, na);
+                    cur = cur + 1;
+                    continue;
+                }
+                if (leaf_intersect<true, PACKET, COUNT>(sc, na, nf, m, r, maxT, dummy, tr)) return true;
+            }
+            if (sp == 0) break;
+            cur = st.get(--sp);
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------- surface + material
+struct Surface { // mesh.h:17-27; dp/duv are re-fetched from the bump record by prim when needed
+    Vec3 normal;
+    Vec2 uv;
+    uint32_t mat;  // global material index
+    uint32_t prim; // global triangle index (mesh order)
+};
+
+// mesh.cpp:311-364
+template <bool COUNT>
+__device__ __forceinline__ void get_surface(const DevScene& sc, const DevHit& h, Surface& s, Traffic& tr)
+{
+    if (COUNT) tr.nHit++;
+    uint32_t gp = sc.primBase[h.meshId] + h.primId;
+    const float4* sp = sc.shade + 4 * (size_t)gp;
+    float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+    if (sc.hasNormals[h.meshId]) {
+        Vec3 n = add3(add3(scale3(h.i, mk3(s0.x, s0.y, s0.z)), scale3(h.j, mk3(s1.x, s1.y, s1.z))), scale3(h.k, mk3(s2.x, s2.y, s2.z)));
+        s.normal = normalize3(n);
+    } else {
+        s.normal = mk3(s0.x, s0.y, s0.z); // normalize(cross(p1-p0,p2-p0)) precomputed with the same operations
+    }
+    s.uv = Vec2{h.i * s1.w + h.j * s3.x + h.k * s3.z, h.i * s2.w + h.j * s3.y + h.k * s3.w};
+    s.mat = asu(s0.w);
+    s.prim = gp;
+}
+
+// material.cpp:87-96 (degamma :24-28 needs powf: see prt_powf in prt_devmath.h)
+template <bool COUNT>
+__device__ __forceinline__ Vec3 sample_diffuse(const DevScene& sc, uint32_t mat, Vec2 uv, Traffic& tr)
+{
+    const float4* mp = sc.mats + 3 * (size_t)mat;
+    float4 m0 = mp[0], m2 = mp[2];
+    Vec3 color = mk3(m0.x, m0.y, m0.z);
+    int32_t tex = (int32_t)asu(m2.x);
+    if (tex >= 0) {
+        Vec3 c = tex_sample3<COUNT>(sc, (uint32_t)tex, uv, tr);
+        color = mul3(color, mk3(prt_powf_2p2(c.x), prt_powf_2p2(c.y), prt_powf_2p2(c.z)));
+    }
+    return color;
+}
+
+// material.cpp:98-114
+template <bool COUNT>
+__device__ __forceinline__ Vec3 sample_bump(const DevScene& sc, uint32_t mat, const Surface& s, Traffic& tr)
+{
+    Vec3 normal = s.normal;
+    const float4* mp = sc.mats + 3 * (size_t)mat;
+    int32_t tex = (int32_t)asu(mp[2].y);
+    if (tex >= 0) {
+        const float4* bp = sc.bump + 3 * (size_t)s.prim;
+        float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        Vec3 dp01 = mk3(b0.x, b0.y, b0.z), dp02 = mk3(b1.x, b1.y, b1.z);
+        Vec2 duv01 = Vec2{b0.w, b1.w}, duv02 = Vec2{b2.x, b2.y};
+        uint4 d = sc.texDesc[tex];
+        float onePixel = 0.5f / (float)(int32_t)d.y + 0.5f / (float)(int32_t)d.z; // texture.h:26
+        float b = tex_sample1<COUNT>(sc, (uint32_t)tex, s.uv, tr);
+        float b01 = tex_sample1<COUNT>(sc, (uint32_t)tex, Vec2{s.uv.x + onePixel * duv01.x, s.uv.y + onePixel * duv01.y}, tr) - b;
+        float b02 = tex_sample1<COUNT>(sc, (uint32_t)tex, Vec2{s.uv.x + onePixel * duv02.x, s.uv.y + onePixel * duv02.y}, tr) - b;
+        float nk = 4.0f;
+        normal = normalize3(add3(add3(normal, scale3(nk * b01, dp01)), scale3(nk * b02, dp02)));
+    }
+    return normal;
+}
+
+// ---------------------------------------------------------------------------- RNG (random.h:23-48)
+__device__ __forceinline__ uint32_t xorshift32(uint32_t x)
+{
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+}
+__device__ __forceinline__ float rng_to_float(uint32_t u) { return asf((u & 0x007fffffu) | 0x3f800000u) - 1.0f; }
+__device__ __forceinline__ uint32_t pixel_seed(uint32_t x, uint32_t y, uint32_t width, uint32_t seed)
+{
+    uint32_t h = x + y * width + seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h | 1u;
+}

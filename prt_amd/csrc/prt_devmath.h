@@ -96,3 +96,112 @@ PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
         *cosp = (float)cres;
     }
 }
+
+// powf(x, 2.2f) for x >= 0 as glibc 2.35 computes it (sysdeps/ieee754/flt-32/e_powf.c: log2 by a
+// 16-entry table + degree-5 polynomial in double, exp2 by a 32-entry table + cubic), restated
+// from the published algorithm.  material.cpp:24-28 (degamma) is the only caller on the path;
+// its arguments are bilinear texel mixes in [0, 1].  Checked against the box's libm over every
+// float in [2^-24, 1] by tests/test_devmath.py.
+PRT_HD double prt_u2d(uint64_t u)
+{
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+}
+PRT_HD uint64_t prt_d2u(double d)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &d, 8);
+    return u;
+}
+
+PRT_HD void prt_powf_log2_tab(int i, double* invc, double* logc)
+{
+    // c near the centre of the i-th sixteenth of [0x1.66p-1, 0x1.66p0): invc ~ 1/c, logc ~ log2(c)
+    switch (i) {
+    case 0: *invc = 0x1.661ec79f8f3bep+0; *logc = -0x1.efec65b963019p-2; break;
+    case 1: *invc = 0x1.571ed4aaf883dp+0; *logc = -0x1.b0b6832d4fca4p-2; break;
+    case 2: *invc = 0x1.49539f0f010bp+0; *logc = -0x1.7418b0a1fb77bp-2; break;
+    case 3: *invc = 0x1.3c995b0b80385p+0; *logc = -0x1.39de91a6dcf7bp-2; break;
+    case 4: *invc = 0x1.30d190c8864a5p+0; *logc = -0x1.01d9bf3f2b631p-2; break;
+    case 5: *invc = 0x1.25e227b0b8eap+0; *logc = -0x1.97c1d1b3b7afp-3; break;
+    case 6: *invc = 0x1.1bb4a4a1a343fp+0; *logc = -0x1.2f9e393af3c9fp-3; break;
+    case 7: *invc = 0x1.12358f08ae5bap+0; *logc = -0x1.960cbbf788d5cp-4; break;
+    case 8: *invc = 0x1.0953f419900a7p+0; *logc = -0x1.a6f9db6475fcep-5; break;
+    case 9: *invc = 0x1p+0; *logc = 0x0p+0; break;
+    case 10: *invc = 0x1.e608cfd9a47acp-1; *logc = 0x1.338ca9f24f53dp-4; break;
+    case 11: *invc = 0x1.ca4b31f026aap-1; *logc = 0x1.476a9543891bap-3; break;
+    case 12: *invc = 0x1.b2036576afce6p-1; *logc = 0x1.e840b4ac4e4d2p-3; break;
+    case 13: *invc = 0x1.9c2d163a1aa2dp-1; *logc = 0x1.40645f0c6651cp-2; break;
+    case 14: *invc = 0x1.886e6037841edp-1; *logc = 0x1.88e9c2c1b9ff8p-2; break;
+    default: *invc = 0x1.767dcf5534862p-1; *logc = 0x1.ce0a44eb17bccp-2; break;
+    }
+}
+
+PRT_HD float prt_powf_2p2(float x)
+{
+    uint32_t ix = prt_f2u(x);
+    if (ix == 0x3f800000u) return 1.0f; // x == 1
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        // zero, subnormal, negative, inf or nan
+        if ((ix << 1) == 0) return 0.0f;                 // pow(+-0, 2.2) = +0
+        if (ix == 0x7f800000u) return x;                 // +inf
+        if (ix > 0x7f800000u) return prt_u2f(0x7fc00000u); // negative or nan -> nan (never on the path)
+        // subnormal: normalise as glibc does (x * 2^23, exponent - 23)
+        ix = prt_f2u(x * 0x1p23f);
+        ix &= 0x7fffffffu;
+        ix -= 23u << 23;
+    }
+    // log2_inline
+    const uint32_t OFF = 0x3f330000u;
+    uint32_t tmp = ix - OFF;
+    int i = (int)((tmp >> (23 - 4)) % 16u);
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int k = (int32_t)top >> 23;
+    double invc, logc;
+    prt_powf_log2_tab(i, &invc, &logc);
+    double z = (double)prt_u2f(iz);
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    double r = prt_mad(z, invc, -1.0);
+    double y0 = logc + (double)k;
+    double r2 = r * r;
+    double y = prt_mad(A0, r, A1);
+    double p = prt_mad(A2, r, A3);
+    double r4 = r2 * r2;
+    double q = prt_mad(A4, r, y0);
+    q = prt_mad(p, r2, q);
+    y = prt_mad(y, r4, q);
+    double ylogx = (double)2.2f * y;
+    // (overflow/underflow of the result cannot happen for x in [0,1], y = 2.2: 2.2*log2(x) > -330 only matters
+    //  below 2^-57; such inputs underflow to the correctly signed 0/denormal through the scaling below)
+    if (ylogx <= -150.0) return 0.0f;
+    // exp2_inline, N = 32, no sign bias
+    const double SHIFT = 0x1.8p+52 / 32.0;
+    double kd = ylogx + SHIFT;
+    uint64_t ki = prt_d2u(kd);
+    kd -= SHIFT;
+    double rr = ylogx - kd;
+    // T[j] = bits(2^(j/32)) - (j << 47)
+    const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+    };
+    uint64_t t = T[ki % 32u];
+    t += ki << (52 - 5);
+    double s = prt_u2d(t);
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double zz = prt_mad(C0, rr, C1);
+    double rr2 = rr * rr;
+    double yy = prt_mad(C2, rr, 1.0);
+    yy = prt_mad(zz, rr2, yy);
+    yy = yy * s;
+    return (float)yy;
+}

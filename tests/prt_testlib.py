@@ -130,6 +130,8 @@ def oracle():
     L.orc_render.argtypes = [vp, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, vp,
                              C.POINTER(OrcStats)]
     L.orc_max_threads.restype = C.c_int
+    L.orc_libm_sincos.argtypes = [C.c_uint32, vp, vp, vp]
+    L.orc_libm_powf22.argtypes = [C.c_uint32, vp, vp]
     _oracle = L
     return L
 
@@ -422,3 +424,24 @@ def cornell_scene(width, height, with_teapot=True):
     if with_teapot:
         meshes.append(oracle_vertex_normals(load_teapot_mesh()))
     return SceneDesc(meshes, cam_pos=(0, 0.965, 2.6), cam_dir=(0, 0, -1.0), width=width, height=height)
+
+
+def scene_desc_from_product(scene, camera, exposure=1.0):
+    """SceneDesc (for the oracle / reference harness) holding the same arrays the product uploads."""
+    a = scene.arrays()
+    meshes = [MeshDesc(m["indices"], m["positions"], m["prim_material"], m["materials"].view(MATERIAL_DTYPE), normals=m["normals"],
+                       texcoords=m["texcoords"]) for m in a["meshes"]]
+    light = (a["light_dir"], a["light_intensity"]) if a["has_light"] else None
+    d = SceneDesc(meshes, np.array(camera.desc.pos[:], dtype=np.float32), np.array(camera.desc.dir[:], dtype=np.float32),
+                  camera.width, camera.height, light=light, textures=a["textures"], exposure=exposure)
+    d.product_arrays = a
+    return d
+
+
+def teapot_product_mesh():
+    import prt_amd
+    m = load_teapot_mesh(scale=1.0, translate=(0, 0, 0))
+    pm = prt_amd.Mesh.from_arrays(m.indices, m.positions, m.prim_material, m.materials.view(prt_amd.MATERIAL_DTYPE),
+                                  texcoords=m.texcoords)
+    pm.transform(0.005, (-0.5, 0.0, 0.5))
+    return pm

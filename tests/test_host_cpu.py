@@ -1,0 +1,146 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+scene code (Cornell data, OBJ-free teapot arrays, BVH build, vertex normals, camera) agrees bit for bit
+with the oracle and with the golden vectors of the compiled reference, and the device math header
+reproduces libm on the arguments the path produces."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import prt_amd
+import prt_testlib as T
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def L():
+    prt_amd.build()
+    return prt_amd.lib()
+
+
+def test_library_exports_every_declared_symbol(L):
+    declared = set()
+    for h in ("prt_hip.h", "prt_host.h"):
+        src = open(os.path.join(T.ROOT, "include", h)).read()
+        declared |= set(re.findall(r"\b(prt_(?:hip|host)_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(prt_amd.EXPORTS), declared ^ set(prt_amd.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_gpu_means_loud_failure(L):
+    if L.prt_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(prt_amd.PrtError, match="no HIP device"):
+        prt_amd.PathTracer()
+
+
+def test_product_never_links_the_oracle():
+    """The oracle is the checker: nothing under prt_amd/ (or the drop-in example) may include, import or link it."""
+    out = subprocess.check_output(["ldd", prt_amd.LIB_PATH]).decode()
+    assert "oracle" not in out
+    pat = re.compile(r"prt_oracle|liboracle|orc_[a-z_]+\(|import\s+prt_testlib|oracle/")
+    for top in ("prt_amd", "examples", "include"):
+        for root, _, files in os.walk(os.path.join(T.ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".h", ".hip", ".inc")):
+                    text = open(os.path.join(root, f)).read()
+                    assert not pat.search(text), os.path.join(root, f)
+
+
+def _teapot_mesh():
+    m = T.load_teapot_mesh(scale=1.0, translate=(0, 0, 0))
+    pm = prt_amd.Mesh.from_arrays(m.indices, m.positions, m.prim_material, m.materials.view(prt_amd.MATERIAL_DTYPE), texcoords=m.texcoords)
+    pm.transform(0.005, (-0.5, 0.0, 0.5))
+    return pm
+
+
+def test_cornell_teapot_scene_matches_reference_vectors(L):
+    scene, camera, _ = prt_amd.setup_cornell_box(512, 512, teapot_mesh=_teapot_mesh())
+    a = scene.arrays()
+    z = np.load(os.path.join(T.GOLDEN, "bvh_cornell_teapot.npz"))
+    gc = T.load_cornell_mesh()
+    assert (a["meshes"][0]["indices"] == gc.indices).all()
+    assert (bits(a["meshes"][0]["positions"]) == bits(gc.positions)).all()
+    assert a["meshes"][0]["materials"].tobytes() == gc.materials.tobytes()
+    assert (bits(a["meshes"][1]["normals"]) == bits(z["teapot_normals"])).all()
+    for i in range(2):
+        ref = z[f"nodes{i}"].view(T.NODE_DTYPE).reshape(-1)
+        got = a["meshes"][i]["nodes"]
+        assert len(got) == len(ref)
+        for f in ("primOrSecondNodeIndex", "primCount", "splitAxis"):
+            assert (got[f] == ref[f]).all(), f
+        leaf = ref["primCount"] != 0xF
+        assert (got["triVectorIndex"][leaf] == ref["triVectorIndex"][leaf]).all()
+        assert (bits(got["lower"]) == bits(ref["lower"])).all() and (bits(got["upper"]) == bits(ref["upper"])).all()
+        assert (a["meshes"][i]["remap"] == z[f"remap{i}"]).all()
+    assert (bits(scene.bbox()) == bits(z["scene_bbox"])).all()
+    assert bits(a["radius"]) == bits(z["radius"])
+    cz = np.load(os.path.join(T.GOLDEN, "camera_packets.npz"))["out"][0]
+    cam = np.array(list(camera.desc.pos) + list(camera.desc.dir) + list(camera.desc.up) + list(camera.desc.right), dtype=np.float32)
+    assert (bits(cam) == bits(cz[96:108])).all()
+
+
+def test_obj_reader_matches_teapot_fixture(L):
+    path = "/root/reference/data/teapot/teapot.obj"
+    if not os.path.exists(path):
+        pytest.skip("reference data not present on this box")
+    scene = prt_amd.Scene()
+    m = prt_amd.Mesh.load_obj(path, prt_amd.Material.make(diffuse=(0.9, 0.9, 0.9), reflection=1))
+    scene.add(m)
+    a = scene.arrays()["meshes"][0]
+    z = np.load(os.path.join(T.GOLDEN, "teapot_mesh.npz"))
+    assert (a["indices"] == z["indices"]).all()
+    assert (bits(a["positions"]) == bits(z["positions"])).all()
+    assert (bits(a["texcoords"]) == bits(z["texcoords"])).all()
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (8, 1), (9, 2), (300, 3), (5000, 4)])
+def test_bvh_build_matches_oracle_on_random_soups(L, n, seed):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-1, 1, (3 * n, 3)).astype(np.float32)
+    if seed == 3:
+        pos[:, 1] = 0.25  # flat: zero extent on one axis (bvh.cpp:66)
+    if seed == 4:
+        pos[: 3 * 64] = pos[0]  # many identical centroids: exercises the mid fallback (bvh.cpp:150-153)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    nodes_p, cnt, remap_p = C.POINTER(prt_amd.BvhNode)(), C.c_uint32(), C.POINTER(C.c_uint32)()
+    assert L.prt_host_bvh_build(n, idx.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), 0, C.byref(nodes_p), C.byref(cnt),
+                                C.byref(remap_p)) == 0
+    nodes = np.frombuffer(C.string_at(nodes_p, cnt.value * C.sizeof(prt_amd.BvhNode)), dtype=T.NODE_DTYPE).copy()
+    remap = np.ctypeslib.as_array(remap_p, shape=(n,)).copy()
+    L.prt_host_free(nodes_p)
+    L.prt_host_free(remap_p)
+    mats = np.array([T.make_material(diffuse=(0.5, 0.5, 0.5))], dtype=T.MATERIAL_DTYPE)
+    s = T.OracleScene(T.SceneDesc([T.MeshDesc(idx, pos, np.zeros(n, dtype=np.uint32), mats)], (0, 0, 3), (0, 0, -1), 8, 8))
+    on = s.nodes(0)
+    assert len(on) == len(nodes)
+    assert on.tobytes() == nodes.tobytes()
+    assert (s.prim_remap(0) == remap).all()
+
+
+def test_devmath_matches_libm_on_every_path_argument(tmp_path):
+    """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce; powf(x, 2.2): every float in [2^-24, 1]."""
+    src = tmp_path / "dm.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <math.h>
+#include <string.h>
+#include "%s/prt_amd/csrc/prt_devmath.h"
+int main(){ const float kPi = 3.14159265358979323846f; long bad=0;
+  for(uint32_t k=0;k<(1u<<23);k++){ uint32_t b=k|0x3f800000u; float f; memcpy(&f,&b,4); float theta=2.0f*kPi*(f-1.0f);
+    float s,c; prt_sincosf(theta,&s,&c); float gs=sinf(theta), gc=cosf(theta);
+    if(memcmp(&s,&gs,4)||memcmp(&c,&gc,4)) bad++; }
+  for(uint32_t b=0x33800000u;b<=0x3f800000u;b++){ float x; memcpy(&x,&b,4); float m=prt_powf_2p2(x), g=powf(x,2.2f); if(memcmp(&m,&g,4)) bad++; }
+  float z=0.0f, m=prt_powf_2p2(z), g=powf(z,2.2f); if(memcmp(&m,&g,4)) bad++;
+  printf("%%ld\n", bad); return 0; }
+''' % T.ROOT)
+    exe = tmp_path / "dm"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(src), "-o", str(exe), "-lm"])
+    assert subprocess.check_output([str(exe)]).decode().strip() == "0"
