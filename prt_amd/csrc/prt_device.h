@@ -70,7 +70,7 @@ __device__ __forceinline__ Vec3 cross3(Vec3 a, Vec3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float length3(Vec3 v) { return __fsqrt_rn(dot3(v, v)); }
+__device__ __forceinline__ float length3(Vec3 v) { return sqrtf(dot3(v, v)); }
 __device__ __forceinline__ Vec3 normalize3(Vec3 v) // vecmath.h:1200
 {
     float invlen = 1.0f / length3(v);

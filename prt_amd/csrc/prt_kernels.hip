@@ -46,7 +46,7 @@ __device__ __forceinline__ Vec3 sh3(Vec3 v, uint32_t srcLane) { return mk3(shf(v
 __device__ __forceinline__ Vec3 diffuse_dir(Vec3 normal, float r2, float r1)
 {
     const float kPi = 3.14159265358979323846f;
-    float r2sq = __fsqrt_rn(r2);
+    float r2sq = sqrtf(r2);
     Vec3 u = (fabsf(normal.x) > 0.1f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
     Vec3 tangent = normalize3(cross3(normal, u));
     Vec3 binormal = normalize3(cross3(tangent, normal));
