@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch: rendering the whole image of the workload
+(every pixel, every sample, every bounce) with the scene resident in HBM.  The default workload is
+the configuration BASELINE.json's metric is quoted on -- "Mray/s at 1080p/64spp": config C3, a
+Sponza-class scene at 1920x1080, 64 spp, depth cap 8 on one MI355X (the reference's sponza.obj is not
+shipped; a seeded procedural stand-in of the same triangle count, alpha-masked textures and a bump map is
+used).  With N > 1 the image's 16x16 tiles are dealt round-robin to the ranks (every rank holds
+the whole scene, no data-path collective) and the only exchange is the final image gather over RCCL.
+
+value = rays (the reference's own `raysTraced` definition: primary samples + occlusion rays + scatter rays,
+path_tracer.cpp:62,219,242,276) of the whole job / wall time of the K steps, max over ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (setup function name, kwargs, width, height, spp, maxDepth, description)
+    "c3_sponza_standin": ("setup_atrium_standin", dict(tris=262000, seed=1), 1920, 1080, 64, 8,
+                          "BASELINE config 3: Sponza-class stand-in (262k tris, alpha-masked + bump textures, directional light), "
+                          "1920x1080, 64 spp, depth 8"),
+    "c2_bunny_standin": ("setup_bunny_standin", dict(tris=69451, seed=1), 1024, 1024, 64, 14,
+                         "BASELINE config 2: Cornell box + bunny-class stand-in (69k tris) + directional light, 1024x1024, 64 spp"),
+    "c1_cornell_teapot": ("setup_cornell_box", dict(), 512, 512, 16, 4, "BASELINE config 1: Cornell box (teapot needs the reference's asset), 512x512, 16 spp, depth 4"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+
+
+def algorithmic_bytes(st):
+    """DESIGN.md "Algorithmic bytes": 32 B per node record whose box is tested, 40 B per triangle tested
+    (36 B positions + 4 B remap index), 112 B per surface fetch, 16 B per bilinear tap, 12 B per pixel written."""
+    return 32 * st["nBox"] + 40 * st["nTri"] + 112 * st["nHit"] + 16 * st["nTap"] + 12 * st["nPx"]
+
+
+def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, want_seconds=15.0):
+    """The CPU path timed on this box's host cores (all of them) on a bounded sample of the same workload: a centred
+    window of the image, sized from a quick probe so that the timed run takes about want_seconds.
+
+    kind "reference": the reference's own compiled code (oracle/_ref/ref_path, AVX2 8-wide, built from the reference's
+    sources by oracle/Makefile).  Its depth cap is the literal 14 (path_tracer.cpp:124), so when the workload's cap
+    differs the window is traced at 14 -- Mray/s is a rate, and the oracle port's rate at the workload's own cap is
+    reported beside it ("port_value").  kind "port": oracle/prt_oracle.c (scalar C, OpenMP over tiles) when the
+    reference binary is not there."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import prt_testlib as T
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    W, H = camera.width, camera.height
+    cores = os.cpu_count() or 1
+    s = T.OracleScene(desc)
+
+    def window(frac):
+        w, h = max(16, int(W * frac) // 16 * 16), max(16, int(H * frac) // 16 * 16)
+        x0, y0 = (W - w) // 2 // 16 * 16, (H - h) // 2 // 16 * 16
+        return x0, y0, min(W - 1, x0 + w - 1), min(H - 1, y0 + h - 1)
+
+    def run_port(rect, depth, stats):
+        t0 = time.time()
+        _, st = s.render_rect(rect, spp, max_depth=depth, seed=seed, threads=cores, stats=stats)
+        return time.time() - t0, st["raysTraced"]
+
+    probe = window(0.06)
+    sec, _ = run_port(probe, max_depth, False)
+    frac = min(1.0, 0.06 * (want_seconds / max(sec, 1e-3)) ** 0.5)
+    rect = window(frac)
+    _, rays = run_port(rect, max_depth, True)          # counting pass (not timed)
+    port_sec, _ = run_port(rect, max_depth, False)     # timed pass without counters
+    out = dict(value=rays / port_sec / 1e6, unit="Mray/s", cores=cores, kind="port",
+               sample=f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image at {spp} spp, depth cap {max_depth}: "
+                      f"{rays} rays in {port_sec:.2f} s on {cores} threads (oracle port)")
+    if T.ref_binary("ref_path") is not None:
+        _, rays14 = run_port(rect, 14, True) if max_depth != 14 else (0, rays)
+        _, rst = T.ref_render(desc, spp, rect, seed=seed, threads=cores, stats=False)
+        out = dict(value=rays14 / rst["seconds"] / 1e6, unit="Mray/s", cores=cores, kind="reference", port_value=out["value"],
+                   sample=f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image at {spp} spp: compiled reference "
+                          f"(depth cap 14, its literal) {rays14} rays in {rst['seconds']:.2f} s on {cores} threads; "
+                          f"oracle port at depth cap {max_depth}: {rays} rays in {port_sec:.2f} s")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3_sponza_standin", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--max-depth", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import prt_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: N independent ranks need torchrun
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+
+    setup, kw, W, H, spp, depth, describe = WORKLOADS[args.workload]
+    W, H = args.width or W, args.height or H
+    spp, depth = args.spp or spp, args.max_depth or depth
+    prt_amd.build()
+    scene, camera, exposure = getattr(prt_amd, setup)(W, H, **kw)
+    tracer = prt_amd.PathTracer(device=local_rank, max_depth=depth, seed=args.seed)
+    tracer.upload_scene(scene)
+    tracer.set_camera(camera)
+
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")  # this rank's framebuffer (its tiles; zeros elsewhere)
+    # a non-default torch stream: the kernel is launched on it through the C-ABI, the RCCL gather is ordered behind
+    # it, and the C-ABI's HIP events are recorded on it
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+
+    def step():
+        tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure, rank=rank, nranks=world)
+        if world > 1:
+            # the only exchange: image gather.  Every pixel is non-zero on exactly one rank, so a sum-reduce to rank 0
+            # assembles the image exactly (x + 0 == x); 25 MB at 1080p over xGMI.
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    tracer.stats()  # drop the warm-up launches' events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    st = tracer.stats()
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([st["raysTraced"], st["occludedTraced"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    dt = float(t_all.item())
+    rays_per_step, occl_per_step = float(rays[0].item()), float(rays[1].item())
+    kernel_ms = st["kernelMsSum"] / max(1, st["kernelLaunches"])
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes of THIS rank's launch from an untimed counting launch (deterministic event counts)
+        tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure, rank=rank, nranks=world,
+                            count_traffic=True)
+        torch.cuda.synchronize()
+        ct = tracer.stats()
+        B = algorithmic_bytes(ct)
+        achieved = B / (kernel_ms * 1e-3) / 1e9
+        value = rays_per_step * args.steps / dt / 1e6
+        name, cus = tracer.device_info()
+        out = {
+            "metric": "Mray/s (primary+secondary) at 1080p/64spp; 1/2/4/8-GPU scaling",
+            "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "description": describe, "width": W, "height": H, "spp": spp, "max_depth": depth,
+                       "seed": args.seed, "rays_per_step": int(rays_per_step), "occlusion_rays_per_step": int(occl_per_step),
+                       "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL sum-reduce image gather" if world > 1
+                       else "one GPU", "device": name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "render_kernel<false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": int(B),
+                         "events_per_launch": {k: ct[k] for k in ("nBox", "nTri", "nHit", "nTap", "nPx")}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(scene, camera, exposure, spp, depth, args.seed, args.cpu_seconds)
+            except Exception as e:  # the baseline is a report, never the product
+                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tracer.close()
+
+
+if __name__ == "__main__":
+    main()

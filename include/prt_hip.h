@@ -116,7 +116,9 @@ typedef struct {
     uint64_t occludedTraced; /* path_tracer.cpp:220,243 */
     uint64_t nBox, nTri, nHit, nTap, nPx;
     uint64_t stackOverflow;  /* lanes that needed more than 64 stack entries (must be 0) */
-    double kernelMs;         /* HIP-event time of the last render's kernel */
+    double kernelMs;         /* HIP-event time of the last render's kernel (events on the launch stream) */
+    double kernelMsSum;      /* sum over the render launches since the previous prt_hip_get_stats */
+    uint64_t kernelLaunches; /* number of those launches; the event counters above are of the LAST launch */
 } prt_hip_stats;
 
 /* RayHitT (ray.h:182-198) */

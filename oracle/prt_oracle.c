@@ -1362,7 +1362,13 @@ int orc_max_threads(void)
 void orc_render(const orc_scene* scene, const orc_camera* cam, uint32_t samples, uint32_t maxDepth, uint32_t seed,
                 float exposure, int threads, float* rgb, orc_stats* st)
 {
-    const uint32_t W = cam->width, H = cam->height;
+    orc_render_rect(scene, cam, 0, 0, cam->width - 1, cam->height - 1, samples, maxDepth, seed, exposure, threads, rgb, st);
+}
+
+void orc_render_rect(const orc_scene* scene, const orc_camera* cam, uint32_t rx0, uint32_t ry0, uint32_t rx1, uint32_t ry1,
+                     uint32_t samples, uint32_t maxDepth, uint32_t seed, float exposure, int threads, float* rgb, orc_stats* st)
+{
+    const uint32_t W = rx1 - rx0 + 1, H = ry1 - ry0 + 1;
     const uint32_t tilesX = (W + 15) / 16, tilesY = (H + 15) / 16; /* main.cpp:123-124 tile size */
     orc_stats total;
     memset(&total, 0, sizeof(total));
@@ -1378,9 +1384,9 @@ void orc_render(const orc_scene* scene, const orc_camera* cam, uint32_t samples,
 #endif
         for (int32_t tile = 0; tile < (int32_t)(tilesX * tilesY); tile++) {
             uint32_t tx = (uint32_t)tile % tilesX, ty = (uint32_t)tile / tilesX;
-            uint32_t x0 = tx * 16, y0 = ty * 16;
-            uint32_t x1 = x0 + 15 < W - 1 ? x0 + 15 : W - 1;
-            uint32_t y1 = y0 + 15 < H - 1 ? y0 + 15 : H - 1;
+            uint32_t x0 = rx0 + tx * 16, y0 = ry0 + ty * 16;
+            uint32_t x1 = x0 + 15 < rx1 ? x0 + 15 : rx1;
+            uint32_t y1 = y0 + 15 < ry1 ? y0 + 15 : ry1;
             orc_trace_block(scene, cam, x0, y0, x1, y1, samples, maxDepth, seed, exposure, rgb, st ? &local : NULL);
         }
 #ifdef _OPENMP

@@ -143,6 +143,9 @@ void orc_trace_block(const orc_scene*, const orc_camera*, uint32_t x0, uint32_t 
 /* whole image over `threads` OpenMP threads (0 = all); same results as orc_trace_block */
 void orc_render(const orc_scene*, const orc_camera*, uint32_t samples, uint32_t maxDepth, uint32_t seed,
                 float exposure, int threads, float* rgb, orc_stats* st);
+/* the same over an inclusive pixel rectangle (used for the bounded CPU-baseline sample of bench.py) */
+void orc_render_rect(const orc_scene*, const orc_camera*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t samples,
+                     uint32_t maxDepth, uint32_t seed, float exposure, int threads, float* rgb, orc_stats* st);
 int orc_max_threads(void);
 
 /* ---- explicit-argument leaf functions: mesh.cpp:311-364, texture.cpp:142-156, material.cpp:87-114 ---- */

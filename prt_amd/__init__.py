@@ -77,10 +77,11 @@ class RenderParams(C.Structure):
 
 class HipStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx",
-                                          "stackOverflow")] + [("kernelMs", C.c_double)]
+                                          "stackOverflow")] + [("kernelMs", C.c_double), ("kernelMsSum", C.c_double),
+                                                               ("kernelLaunches", C.c_uint64)]
 
     def as_dict(self):
-        return {n: (float(getattr(self, n)) if n == "kernelMs" else int(getattr(self, n))) for n, _ in self._fields_}
+        return {n: (float(getattr(self, n)) if n.startswith("kernelMs") else int(getattr(self, n))) for n, _ in self._fields_}
 
 
 class Hit(C.Structure):

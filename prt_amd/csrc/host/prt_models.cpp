@@ -399,9 +399,9 @@ Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMaske
     };
     enum { kFloor = 0, kWall, kColumn, kArch, kRoof, kCardFirst };
     const uint32_t kCardMaterials = 8;
-    // budget: 30% shell, 50% columns+arches, 20% cards
+    // budget: 25% shell, 40% columns, 15% arches, 20% cards
     const float L = 36.0f, W = 14.0f, H = 12.0f;
-    uint32_t shellCells = std::max(2u, (uint32_t)std::sqrt((double)targetTris * 0.30 / (2.0 * 5.2)));
+    uint32_t shellCells = std::max(2u, (uint32_t)std::sqrt((double)targetTris * 0.25 / 18.7));
     uint32_t nL = shellCells * 2, nW = shellCells, nH = shellCells;
     patch(Vector3f(-L / 2, 0, W / 2), Vector3f(L, 0, 0), Vector3f(0, 0, -W), nL, nW, kFloor, 8.0f);            // floor (+y)
     patch(Vector3f(-L / 2, 0, -W / 2), Vector3f(L, 0, 0), Vector3f(0, H, 0), nL, nH, kWall, 4.0f);             // back wall (+z)
@@ -413,7 +413,7 @@ Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMaske
     patch(Vector3f(-L / 2, H, W * 0.2f), Vector3f(L, 0, 0), Vector3f(0, 0, W * 0.3f), nL, std::max(1u, nW / 3), kRoof, 4.0f);
     // columns: two rows of 10, faceted cylinders with entasis; arches between neighbours
     const uint32_t colCount = 20;
-    uint32_t colTris = (uint32_t)((double)targetTris * 0.36 / colCount);
+    uint32_t colTris = (uint32_t)((double)targetTris * 0.40 / colCount);
     uint32_t cs = std::max(6u, (uint32_t)std::sqrt((double)colTris / 2.0 * 0.5)), ch = std::max(2u, colTris / (2 * cs));
     const float kPiF = 3.14159265358979323846f;
     for (uint32_t c = 0; c < colCount; c++) {
@@ -432,8 +432,7 @@ Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMaske
                 tri(v1, v2, v3, kColumn);
             }
     }
-    uint32_t archTris = (uint32_t)((double)targetTris * 0.14 / 18.0);
-    uint32_t as = std::max(4u, archTris / 8);
+    uint32_t as = std::max(4u, (uint32_t)((double)targetTris * 0.15 / 108.0)); // 18 arches x 6 triangles per step
     for (uint32_t c = 0; c < colCount; c++) {
         if (c % 10 == 9) continue;
         float x0 = -L / 2 + L * ((float)(c % 10) + 0.5f) / 10.0f, x1 = x0 + L / 10.0f, cz = (c < 10) ? -W * 0.28f : W * 0.28f;
@@ -472,9 +471,30 @@ Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMaske
     uint32_t have = (uint32_t)I.size() / 3;
     uint32_t cardTris = targetTris > have ? targetTris - have : 0;
     uint32_t cards = cardTris / 2;
+    // clustered like potted plants at the column bases and hanging baskets under the arches, so that most of the
+    // hall stays open to the light
+    const uint32_t kClusters = 48;
+    Vector3f cc[kClusters];
+    float cr[kClusters];
+    for (uint32_t k = 0; k < kClusters; k++) {
+        uint32_t col = k % colCount;
+        float cx = -L / 2 + L * ((float)(col % 10) + 0.5f) / 10.0f, cz = (col < 10) ? -W * 0.28f : W * 0.28f;
+        bool hanging = k >= colCount && k < 2 * colCount;
+        if (k >= 2 * colCount) { // along the walls
+            cx = rng.range(-L / 2 + 2, L / 2 - 2);
+            cz = (k & 1) ? -W / 2 + 0.9f : W / 2 - 0.9f;
+        }
+        cc[k] = Vector3f(cx + (hanging ? L / 20.0f : rng.range(-0.9f, 0.9f)), hanging ? 6.2f : rng.range(0.5f, 1.2f),
+                         cz + (hanging ? 0.0f : rng.range(-0.9f, 0.9f)));
+        cr[k] = hanging ? 0.55f : rng.range(0.5f, 0.9f);
+    }
     for (uint32_t c = 0; c < cards; c++) {
-        Vector3f centre(rng.range(-L / 2 + 1, L / 2 - 1), rng.range(0.3f, H - 1.0f), rng.range(-W / 2 + 0.5f, W / 2 - 0.5f));
-        float a = rng.range(0.0f, 2.0f * kPiF), tilt = rng.range(-0.6f, 0.6f), sz = rng.range(0.08f, 0.35f);
+        uint32_t k = rng.next() % kClusters;
+        // rejection-free point in a ball: direction * radius^(1/3)
+        float u1 = rng.range(-1.0f, 1.0f), ph = rng.range(0.0f, 2.0f * kPiF), rr = cr[k] * std::cbrt(rng.uniform());
+        float sq = std::sqrt(std::fmax(0.0f, 1.0f - u1 * u1));
+        Vector3f centre = cc[k] + Vector3f(rr * sq * std::cos(ph), rr * u1, rr * sq * std::sin(ph));
+        float a = rng.range(0.0f, 2.0f * kPiF), tilt = rng.range(-0.9f, 0.9f), sz = rng.range(0.04f, 0.11f);
         Vector3f u(std::cos(a) * sz, std::sin(tilt) * sz, std::sin(a) * sz);
         Vector3f v(-std::sin(a) * std::sin(tilt) * sz, std::cos(tilt) * sz, std::cos(a) * std::sin(tilt) * sz);
         uint32_t m = kCardFirst + (rng.next() % kCardMaterials);

@@ -517,7 +517,8 @@ inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 struct prt_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per render launch since the last get_stats
+    size_t eventsUsed = 0;
     int computeUnits = 0;
     std::string name;
     // scene
@@ -572,10 +573,8 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->computeUnits = prop.multiProcessorCount;
-    c->name = prop.name;
+    c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc(&c->work, 256));
     HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
@@ -600,8 +599,10 @@ void prt_hip_destroy(prt_hip_ctx* c)
     if (c->work) (void)hipFree(c->work);
     if (c->counters) (void)hipFree(c->counters);
     if (c->spill) (void)hipFree(c->spill);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& e : c->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -845,12 +846,20 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     A.spillStride = c->spillThreads;
     HIP_TRY(hipMemsetAsync(c->work, 0, sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), s));
-    HIP_TRY(hipEventRecord(c->ev0, s));
+    if (c->eventsUsed == c->events.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        c->events.emplace_back(a, b);
+    }
+    hipEvent_t ev0 = c->events[c->eventsUsed].first, ev1 = c->events[c->eventsUsed].second;
+    c->eventsUsed++;
+    HIP_TRY(hipEventRecord(ev0, s));
     if (p->countTraffic) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
     else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("render_kernel launch: ") + hipGetErrorString(le));
-    HIP_TRY(hipEventRecord(c->ev1, s));
+    HIP_TRY(hipEventRecord(ev1, s));
     c->timed = true;
     return PRT_HIP_OK;
 }
@@ -888,10 +897,17 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     st->nPx = h[6];
     st->stackOverflow = h[7];
     st->kernelMs = 0.0;
-    if (c->timed) {
+    st->kernelMsSum = 0.0;
+    st->kernelLaunches = 0;
+    for (size_t i = 0; i < c->eventsUsed; i++) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) st->kernelMs = ms;
+        if (hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second) == hipSuccess) {
+            st->kernelMs = ms;
+            st->kernelMsSum += ms;
+            st->kernelLaunches++;
+        }
     }
+    c->eventsUsed = 0;
     if (h[7]) return fail(PRT_HIP_ESTACK, "BVH traversal needed more than 64 stack entries (the reference asserts here, bvh.cpp:552)");
     return PRT_HIP_OK;
 }

@@ -130,6 +130,7 @@ def oracle():
     L.orc_render.argtypes = [vp, C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, vp,
                              C.POINTER(OrcStats)]
     L.orc_max_threads.restype = C.c_int
+    L.orc_render_rect.argtypes = [vp, C.POINTER(OrcCamera)] + [C.c_uint32] * 7 + [C.c_float, C.c_int, vp, C.POINTER(OrcStats)]
     L.orc_libm_sincos.argtypes = [C.c_uint32, vp, vp, vp]
     L.orc_libm_powf22.argtypes = [C.c_uint32, vp, vp]
     _oracle = L
@@ -275,6 +276,16 @@ class OracleScene:
         self.L.orc_render(self.scene, C.byref(self.camera), spp, max_depth, seed, d.exposure, threads, vptr(rgb),
                           C.byref(st) if stats else None)
         return rgb, st.as_dict()
+
+    def render_rect(self, rect, spp, max_depth=14, seed=12345, threads=0, stats=True):
+        """Multi-threaded render of an inclusive rectangle; returns (crop, stats)."""
+        d = self.desc
+        x0, y0, x1, y1 = rect
+        rgb = np.zeros((d.height, d.width, 3), dtype=np.float32)
+        st = OrcStats()
+        self.L.orc_render_rect(self.scene, C.byref(self.camera), x0, y0, x1, y1, spp, max_depth, seed, d.exposure, threads,
+                               vptr(rgb), C.byref(st) if stats else None)
+        return rgb[y0:y1 + 1, x0:x1 + 1].copy(), st.as_dict()
 
     def trace_block(self, x0, y0, x1, y1, spp, max_depth=14, seed=12345):
         d = self.desc
