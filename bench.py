@@ -47,6 +47,28 @@ def algorithmic_bytes(st):
     return 32 * st["nBox"] + 40 * st["nTri"] + 112 * st["nHit"] + 16 * st["nTap"] + 12 * st["nPx"]
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a
+    1-GPU job a share of the host, not all of os.cpu_count())."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("PRT_BENCH_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, want_seconds=15.0):
     """The CPU path timed on this box's host cores (all of them) on a bounded sample of the same workload: a centred
     window of the image, sized from a quick probe so that the timed run takes about want_seconds.
@@ -60,7 +82,7 @@ def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, want_seconds=15.
     import prt_testlib as T
     desc = T.scene_desc_from_product(scene, camera, exposure)
     W, H = camera.width, camera.height
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     s = T.OracleScene(desc)
 
     def window(frac):

@@ -887,7 +887,10 @@ static int intersect_single_leaf(const orc_scene* s, const orc_bvh* b, const orc
         if (!(t >= kTriEpsilon && t < maxT)) continue;
         if (tv->alphaTest[lane]) {
             const orc_material* mat = &m->materials[m->primMaterial[primIndices[lane]]];
-            if (!tex_test_alpha(&s->textures[mat->diffuseMap], tri_uv(tv, (int)lane, ijk), 0, st)) continue;
+            /* nTap counts NECESSARY taps: a candidate that is not nearer than the best of this leaf so far cannot
+             * change the result, whatever its alpha (the reference still samples it, bvh.cpp:328-340) */
+            orc_stats* cst = (mode == 1 || nearestT > t) ? st : NULL;
+            if (!tex_test_alpha(&s->textures[mat->diffuseMap], tri_uv(tv, (int)lane, ijk), 0, cst)) continue;
         }
         if (mode == 0) {
             if (nearestT > t) {
@@ -931,7 +934,10 @@ static uint32_t intersect_packet_leaf(const orc_scene* s, const orc_bvh* b, cons
             uint32_t primIndex = primIndices[i];
             if (tv->alphaTest[i]) {
                 const orc_material* mat = &m->materials[m->primMaterial[primIndex]];
-                if (!tex_test_alpha(&s->textures[mat->diffuseMap], tri_uv(tv, (int)i, ijk), 1, st)) continue;
+                /* necessary taps only (see intersect_single_leaf): a lane already occluded by an earlier triangle of
+                 * this leaf needs no further alpha test, although the reference keeps testing it (bvh.cpp:376-424) */
+                orc_stats* cst = (mode == 1 && (res & (1u << l))) ? NULL : st;
+                if (!tex_test_alpha(&s->textures[mat->diffuseMap], tri_uv(tv, (int)i, ijk), 1, cst)) continue;
             }
             if (mode == 0) {
                 hits[l].t = t; hits[l].i = ijk[0]; hits[l].j = ijk[1]; hits[l].k = ijk[2];

@@ -301,6 +301,8 @@ class Camera:
         self.desc = CameraDesc()
 
     def create(self, pos, direction, width, height):
+        self.pos_arg = np.asarray(pos, dtype=np.float32)        # the arguments as given (the basis in desc is derived)
+        self.dir_arg = np.asarray(direction, dtype=np.float32)
         lib().prt_host_camera_create(_f3(pos), _f3(direction), width, height, C.byref(self.desc))
         return self
 

@@ -443,8 +443,9 @@ def scene_desc_from_product(scene, camera, exposure=1.0):
     meshes = [MeshDesc(m["indices"], m["positions"], m["prim_material"], m["materials"].view(MATERIAL_DTYPE), normals=m["normals"],
                        texcoords=m["texcoords"]) for m in a["meshes"]]
     light = (a["light_dir"], a["light_intensity"]) if a["has_light"] else None
-    d = SceneDesc(meshes, np.array(camera.desc.pos[:], dtype=np.float32), np.array(camera.desc.dir[:], dtype=np.float32),
-                  camera.width, camera.height, light=light, textures=a["textures"], exposure=exposure)
+    # Camera::create's ARGUMENTS (camera.desc.dir is already normalised; the basis depends on the raw direction)
+    d = SceneDesc(meshes, camera.pos_arg, camera.dir_arg, camera.width, camera.height, light=light, textures=a["textures"],
+                  exposure=exposure)
     d.product_arrays = a
     return d
 

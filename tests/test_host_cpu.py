@@ -87,6 +87,16 @@ def test_cornell_teapot_scene_matches_reference_vectors(L):
     assert (bits(cam) == bits(cz[96:108])).all()
 
 
+def test_camera_basis_matches_oracle_for_oblique_views(L):
+    for pos, d in (((-15.0, 4.0, 0.5), (1.0, 0.08, -0.05)), ((9, 2.0, 10.2), (0.4, 0.1, -1)), ((0, 5, 0), (0, -1, 0))):
+        cam = prt_amd.Camera().create(pos, d, 1920, 1080)
+        oc = T.OrcCamera()
+        T.oracle().orc_camera_create(C.byref(oc), T.f3(pos), T.f3(d), 1920, 1080)
+        for f in ("pos", "dir", "up", "right"):
+            assert (bits(np.array(getattr(cam.desc, f)[:], dtype=np.float32)) == bits(np.array(getattr(oc, f)[:], dtype=np.float32))).all(), f
+        assert cam.desc.invWidth == oc.invWidth and cam.desc.invHeight == oc.invHeight
+
+
 def test_obj_reader_matches_teapot_fixture(L):
     path = "/root/reference/data/teapot/teapot.obj"
     if not os.path.exists(path):
