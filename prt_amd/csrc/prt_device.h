@@ -12,14 +12,14 @@
 #include "prt_devmath.h"
 
 #define PRT_MAX_BVH 8
-#define PRT_STACK_LDS 24     // stack entries per lane kept in LDS
+#define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (reference + entry distance: 8 B each)
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
 
 // ---------------------------------------------------------------------------- device scene
-// nodes:  2 x float4 per node  {lo.x lo.y lo.z hi.x} {hi.y hi.z a b}
-//         internal: a = index of the second child, b = 0x80000000 | splitAxis   (first child = i + 1)
-//         leaf:     a = first triangle record,     b = primCount
+// wnodes: 4 x float4 (64 B) per INTERNAL node: {lo0.xyz hi0.x} {hi0.yz lo1.xy} {lo1.z hi1.xyz} {ref0 ref1 splitAxis 0}
+//         child 0 is the reference's node i+1, child 1 its m_nodes[primOrSecondNodeIndex]; refs: see PRT_REF_LEAF
+// roots:  per BVH the root's reference and box (rootRef, rootBox)
 // tris:   3 x float4 per triangle in primRemapping order {p0 primId} {p1 alphaRef} {p2 0}
 //         alphaRef = 0, or 1 + index of the alpha record
 // shade:  4 x float4 per triangle in MESH order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
@@ -28,7 +28,7 @@
 // mats:   3 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0}
 // alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
 struct DevScene {
-    const float4* nodes;
+    const float4* wnodes;
     const float4* tris;
     const float4* shade;
     const float4* bump;
@@ -37,7 +37,8 @@ struct DevScene {
     const uint4* texDesc; // {byte offset, width, height, component}
     const uint8_t* texels;
     uint32_t bvhCount;
-    uint32_t root[PRT_MAX_BVH];
+    uint32_t rootRef[PRT_MAX_BVH];
+    float rootBox[PRT_MAX_BVH][6];
     uint32_t primBase[PRT_MAX_BVH];
     uint32_t hasNormals[PRT_MAX_BVH];
     uint32_t hasLight;
@@ -85,7 +86,19 @@ __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 struct DevRay {
     Vec3 org, dir, inv;
     bool swapXZ, swapYZ;
+    // per-ray constants of the watertight test (triangle.cpp:118-119): 1/d.z and (d.x, d.y)/d.z AFTER the axis swap
+    float invDz, shearX, shearY;
 };
+
+__device__ __forceinline__ void prepare_shear(DevRay& r)
+{
+    Vec3 d = r.dir;
+    if (r.swapXZ) { float t = d.x; d.x = d.z; d.z = t; }
+    if (r.swapYZ) { float t = d.y; d.y = d.z; d.z = t; }
+    r.invDz = 1.0f / d.z;
+    r.shearX = d.x * r.invDz;
+    r.shearY = d.y * r.invDz;
+}
 
 struct DevHit {
     float t, i, j, k;
@@ -105,6 +118,7 @@ __device__ __forceinline__ void prepare_single(DevRay& r)
     else e = (r.dir.y > r.dir.z) ? 1u : 2u;
     r.swapXZ = (e == 0u);
     r.swapYZ = (e == 1u);
+    prepare_shear(r);
 }
 
 // ray.h:58-71: largest |component|, x wins ties, then y
@@ -116,6 +130,7 @@ __device__ __forceinline__ void prepare_soa(DevRay& r)
     bool mx = (max_e == ax);
     r.swapXZ = mx;
     r.swapYZ = (max_e == ay) && !mx;
+    prepare_shear(r);
 }
 
 // ---------------------------------------------------------------------------- box tests
@@ -164,29 +179,35 @@ __device__ __forceinline__ bool box_soa(const Box& b, const DevRay& r, float max
     return (max_t0 < maxT) && (min_t1 >= max_t0);
 }
 
+// the hit.t-independent part of box_soa: max_t0 when min_t1 >= max_t0, else +inf (so that `entry < hit.t` is the whole test)
+__device__ __forceinline__ float box_soa_entry(const Box& b, const DevRay& r)
+{
+    float t0[3], t1[3];
+    slabs(b, r, t0, t1);
+    float max_t0 = sse_max(t0[0], sse_max(t0[1], t0[2]));
+    float min_t1 = sse_min(t1[0], sse_min(t1[1], t1[2]));
+    return (min_t1 >= max_t0) ? max_t0 : __builtin_inff();
+}
+
 // ---------------------------------------------------------------------------- triangle
 // triangle.cpp:90-166, one lane.  Returns t, or -1 (kNoIntersection).
 __device__ __forceinline__ float tri_intersect(const DevRay& r, Vec3 p0, Vec3 p1, Vec3 p2, float& bi, float& bj, float& bk)
 {
-    Vec3 d = r.dir;
     Vec3 v0 = sub3(p0, r.org), v1 = sub3(p1, r.org), v2 = sub3(p2, r.org);
     if (r.swapXZ) {
         float t;
-        t = d.x; d.x = d.z; d.z = t;
         t = v0.x; v0.x = v0.z; v0.z = t;
         t = v1.x; v1.x = v1.z; v1.z = t;
         t = v2.x; v2.x = v2.z; v2.z = t;
     }
     if (r.swapYZ) {
         float t;
-        t = d.y; d.y = d.z; d.z = t;
         t = v0.y; v0.y = v0.z; v0.z = t;
         t = v1.y; v1.y = v1.z; v1.z = t;
         t = v2.y; v2.y = v2.z; v2.z = t;
     }
     float v0z = v0.z, v1z = v1.z, v2z = v2.z;
-    float inv_dz = 1.0f / d.z;
-    float idx = d.x * inv_dz, idy = d.y * inv_dz; // invDzD, :119
+    const float inv_dz = r.invDz, idx = r.shearX, idy = r.shearY; // invDzD = inv_dz*d, :119
     float v0x = v0.x - idx * v0z, v0y = v0.y - idy * v0z;
     float v1x = v1.x - idx * v1z, v1y = v1.y - idy * v1z;
     float v2x = v2.x - idx * v2z, v2y = v2.y - idy * v2z;
@@ -284,46 +305,81 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, V
     return (1.0f / 255.0f) * c;
 }
 
-// ---------------------------------------------------------------------------- traversal stack
-// Entries 0..PRT_STACK_LDS-1 of a lane live in LDS ([entry][thread]: conflict-free for any mix of
-// depths), deeper ones in a per-thread global spill area ([entry][thread] as well).
+// ---------------------------------------------------------------------------- traversal
+// Child references.  A traversal never loads a node to learn what it is: the PARENT's record holds both children's
+// boxes and references (one 64-byte fetch per internal node visited, nothing fetched at a pop).
+//   internal: index of the child's own wide record (< 2^30)
+//   leaf:     PRT_REF_LEAF | firstTriangle << 4 | primCount      (primCount 1..8, firstTriangle < 2^27)
+#define PRT_REF_LEAF 0x80000000u
+#define PRT_REF_DEAD 0xffffffffu // counting builds only: a child that failed its box test, kept so that it is counted when popped
+
+// Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper
+// ones in a per-thread global spill area.  `t` (the box entry distance) is only stored by the packet traversal.
 struct Stack {
-    uint32_t* lds;    // &ldsStack[threadIdx.x]
-    uint32_t* spill;  // &spill[globalThread]
+    uint32_t* ldsRef; // &refs[threadIdx.x]
+    float* ldsT;      // &ts[threadIdx.x]
+    uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
     uint32_t spillStride;
-    __device__ __forceinline__ void put(int e, uint32_t v) const
+    __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
-        if (e < PRT_STACK_LDS) lds[e * PRT_BLOCK] = v;
-        else spill[(size_t)(e - PRT_STACK_LDS) * spillStride] = v;
+        if (e < PRT_STACK_LDS) ldsRef[e * PRT_BLOCK] = ref;
+        else spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride] = ref;
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
-        return (e < PRT_STACK_LDS) ? lds[e * PRT_BLOCK] : spill[(size_t)(e - PRT_STACK_LDS) * spillStride];
+        return (e < PRT_STACK_LDS) ? ldsRef[e * PRT_BLOCK] : spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride];
+    }
+    __device__ __forceinline__ void putT(int e, uint32_t ref, float t) const
+    {
+        if (e < PRT_STACK_LDS) {
+            ldsRef[e * PRT_BLOCK] = ref;
+            ldsT[e * PRT_BLOCK] = t;
+        } else {
+            spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride] = ref;
+            spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride] = asu(t);
+        }
+    }
+    __device__ __forceinline__ float getT(int e) const
+    {
+        return (e < PRT_STACK_LDS) ? ldsT[e * PRT_BLOCK] : asf(spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride]);
     }
 };
 
-__device__ __forceinline__ void load_node(const DevScene& sc, uint32_t idx, Box& b, uint32_t& a, uint32_t& f)
+struct WideNode {
+    Box b0, b1;
+    uint32_t ref0, ref1, axis;
+};
+
+__device__ __forceinline__ void load_wide(const DevScene& sc, uint32_t idx, WideNode& w)
 {
-    float4 n0 = sc.nodes[2 * (size_t)idx], n1 = sc.nodes[2 * (size_t)idx + 1];
-    b.lo = mk3(n0.x, n0.y, n0.z);
-    b.hi = mk3(n0.w, n1.x, n1.y);
-    a = asu(n1.z);
-    f = asu(n1.w);
+    const float4* p = sc.wnodes + 4 * (size_t)idx;
+    float4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+    w.b0.lo = mk3(w0.x, w0.y, w0.z);
+    w.b0.hi = mk3(w0.w, w1.x, w1.y);
+    w.b1.lo = mk3(w1.z, w1.w, w2.x);
+    w.b1.hi = mk3(w2.y, w2.z, w2.w);
+    w.ref0 = asu(w3.x);
+    w.ref1 = asu(w3.y);
+    w.axis = asu(w3.z);
 }
 
-#define PRT_NODE_INTERNAL 0x80000000u
-
-// bvh.cpp:302-368 (kNearest / kOcclude).  Returns true when occluded (OCCLUDE only).
-template <bool OCCLUDE, bool PACKET, bool COUNT>
-__device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t triStart, uint32_t primCount, uint32_t meshId,
-                                               const DevRay& r, float maxT, DevHit& hit, Traffic& tr)
+__device__ __forceinline__ Box root_box(const DevScene& sc, uint32_t m)
 {
+    return Box{mk3(sc.rootBox[m][0], sc.rootBox[m][1], sc.rootBox[m][2]), mk3(sc.rootBox[m][3], sc.rootBox[m][4], sc.rootBox[m][5])};
+}
+
+// bvh.cpp:302-368 (kNearest / kOcclude) and :370-427 for one lane.  Returns true when occluded (OCCLUDE only).
+template <bool OCCLUDE, bool PACKET, bool COUNT>
+__device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t ref, uint32_t meshId, const DevRay& r, float maxT, DevHit& hit,
+                                               Traffic& tr)
+{
+    const uint32_t primCount = ref & 15u, triStart = (ref >> 4) & 0x7ffffffu;
     if (COUNT) tr.nTri += primCount;
     // single: candidates need t < maxT with maxT = hit.t at leaf entry, nearest by strict <  (bvh.cpp:323,344)
     // packet: t < hit.t, updated as the loop goes (bvh.cpp:392) -- the same running minimum
     float best = maxT;
-    for (uint32_t i = 0; i < primCount; i++) {
-        const float4* tp = sc.tris + 3 * (size_t)(triStart + i);
+    const float4* tp = sc.tris + 3 * (size_t)triStart;
+    for (uint32_t i = 0; i < primCount; i++, tp += 3) {
         float4 a = tp[0], b = tp[1], c = tp[2];
         float bi, bj, bk;
         float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
@@ -349,7 +405,8 @@ __device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t triS
 }
 
 // Scene::intersect<SingleRayHitPacket,SingleRayPacket> (scene.cpp:47-63) over Bvh::intersect single branch
-// (bvh.cpp:429-570, SORT_CHILDREN): root bool test, both children tested per internal node, near child on top.
+// (bvh.cpp:429-570, SORT_CHILDREN): root bool test, both children tested per internal node against the current
+// hit.t, near child first (t0 < t1, ties -> second child), popped nodes NOT re-tested (bvh.cpp:474).
 template <bool COUNT>
 __device__ __forceinline__ void intersect_single(const DevScene& sc, const DevRay& r, float maxT, DevHit& hit, const Stack& st,
                                                  Traffic& tr, uint32_t& overflow)
@@ -359,50 +416,47 @@ __device__ __forceinline__ void intersect_single(const DevScene& sc, const DevRa
     hit.primId = 0;
     hit.meshId = 0;
     for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        uint32_t cur = sc.root[m];
-        Box nb;
-        uint32_t na, nf;
-        load_node(sc, cur, nb, na, nf);
         if (COUNT) tr.nBox++;
-        if (!box_bool(nb, r, hit.t)) continue;
-        int sp = 0; // number of entries below the node held in `cur`
+        if (!box_bool(root_box(sc, m), r, hit.t)) continue;
+        uint32_t ref = sc.rootRef[m];
+        int sp = 0;
         for (;;) {
-            if (nf & PRT_NODE_INTERNAL) {
-                uint32_t c0 = cur + 1, c1 = na;
-                Box b0, b1;
-                uint32_t a0, f0, a1, f1;
-                load_node(sc, c0, b0, a0, f0);
-                load_node(sc, c1, b1, a1, f1);
+            if (!(ref & PRT_REF_LEAF)) {
+                WideNode w;
+                load_wide(sc, ref, w);
                 if (COUNT) tr.nBox += 2;
-                float t0 = box_t(b0, r), t1 = box_t(b1, r);
+                float t0 = box_t(w.b0, r), t1 = box_t(w.b1, r);
                 bool h0 = t0 < hit.t, h1 = t1 < hit.t;
                 if (h0 && h1) {
-                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
-                    if (t0 < t1) { st.put(sp++, c1); cur = c0; nb = b0; na = a0; nf = f0; }
-                    else { st.put(sp++, c0); cur = c1; nb = b1; na = a1; nf = f1; }
+                    if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; } // bvh.cpp:552
+                    bool near0 = t0 < t1;
+                    st.put(sp++, near0 ? w.ref1 : w.ref0);
+                    ref = near0 ? w.ref0 : w.ref1;
                     continue;
                 } else if (h0) {
-                    cur = c0; na = a0; nf = f0;
+                    ref = w.ref0;
                     continue;
                 } else if (h1) {
-                    cur = c1; na = a1; nf = f1;
+                    ref = w.ref1;
                     continue;
                 }
             } else {
-                leaf_intersect<false, false, COUNT>(sc, na, nf, m, r, hit.t, hit, tr);
+                leaf_intersect<false, false, COUNT>(sc, ref, m, r, hit.t, hit, tr);
             }
             if (sp == 0) break;
-            cur = st.get(--sp);
-            load_node(sc, cur, nb, na, nf);
+            ref = st.get(--sp);
         }
     }
     if (hit.t == maxT) hit.t = -1.0f;
 }
 
-// Scene::intersect<RayHitPacket,RayPacket> for ONE lane of the packet.  The reference walks the 8 rays
-// together with a per-entry lane mask (bvh.cpp:463-569); every mask update and hit update is lane-wise and
-// the visit order depends only on sign(avgDir[splitAxis]) (:523-529), so a lane walking alone over the nodes
-// where its own mask bit is set sees the same nodes in the same order with the same hit.t.
+// Scene::intersect<RayHitPacket,RayPacket> for ONE lane of the packet.  The reference walks the 8 rays together with
+// a per-entry lane mask (bvh.cpp:463-569); every mask and hit update is lane-wise and the visit order depends only on
+// sign(avgDir[splitAxis]) (:523-529), so a lane walking alone over the nodes where its own mask bit is set sees the same
+// nodes in the same order with the same hit.t.  The reference tests a node's box when it is POPPED, against the hit.t
+// of that moment (max_t0 < hit.t && min_t1 >= max_t0, vecmath.h:1504-1518); here the slab distances are computed when
+// the parent is visited (its record holds the child boxes), max_t0 travels on the stack, and the hit.t part of the test
+// is redone at the pop -- the same decision, since max_t0/min_t1 do not depend on hit.t.
 template <bool COUNT>
 __device__ __forceinline__ void intersect_packet(const DevScene& sc, const DevRay& r, uint32_t reverseBits, float maxT, DevHit& hit,
                                                  const Stack& st, Traffic& tr, uint32_t& overflow)
@@ -411,60 +465,92 @@ __device__ __forceinline__ void intersect_packet(const DevScene& sc, const DevRa
     hit.i = hit.j = hit.k = 0.0f;
     hit.primId = 0;
     hit.meshId = 0;
+    const float inf = __builtin_inff();
     for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        uint32_t cur = sc.root[m];
+        if (COUNT) tr.nBox++;
+        if (!box_soa(root_box(sc, m), r, hit.t)) continue;
+        uint32_t ref = sc.rootRef[m];
         int sp = 0;
         for (;;) {
-            Box nb;
-            uint32_t na, nf;
-            load_node(sc, cur, nb, na, nf);
-            if (COUNT) tr.nBox++;
-            if (box_soa(nb, r, hit.t)) {
-                if (nf & PRT_NODE_INTERNAL) {
-                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
-                    // popped first = top of stack: second child unless reverse (bvh.cpp:523-529)
-                    bool rev = (reverseBits >> (nf & 3u)) & 1u;
-                    uint32_t first = rev ? na : cur + 1, later = rev ? cur + 1 : na;
-                    st.put(sp++, later);
-                    cur = first;
-                    continue;
+            bool descend = false;
+            if (!(ref & PRT_REF_LEAF)) {
+                WideNode w;
+                load_wide(sc, ref, w);
+                if (COUNT) tr.nBox += 2; // both children are popped and tested by the reference
+                float e0 = box_soa_entry(w.b0, r), e1 = box_soa_entry(w.b1, r); // max_t0, or +inf when min_t1 < max_t0
+                if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; }
+                // popped first = top of stack: the second child unless reverse (bvh.cpp:523-529)
+                bool rev = (reverseBits >> (w.axis & 3u)) & 1u;
+                uint32_t firstRef = rev ? w.ref1 : w.ref0, laterRef = rev ? w.ref0 : w.ref1;
+                float firstE = rev ? e1 : e0, laterE = rev ? e0 : e1;
+                if (laterE < hit.t) st.putT(sp++, laterRef, laterE); // hit.t only shrinks: failing now means failing at the pop
+                if (firstE < hit.t) {
+                    ref = firstRef;
+                    descend = true;
                 }
-                leaf_intersect<false, true, COUNT>(sc, na, nf, m, r, hit.t, hit, tr);
+            } else {
+                leaf_intersect<false, true, COUNT>(sc, ref, m, r, hit.t, hit, tr);
             }
-            if (sp == 0) break;
-            cur = st.get(--sp);
+            if (descend) continue;
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                float e = st.getT(sp);
+                if (e < hit.t) { // the pop-time test of the reference
+                    ref = st.get(sp);
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
         }
     }
+    (void)inf;
     if (hit.t == maxT) hit.t = -1.0f;
 }
 
 // Scene::occluded (scene.cpp:69-94) over Bvh::occluded (bvh.cpp:576-654); PACKET selects the SoA box test
-// (vecmath.h:1504) and per-lane semantics of the packet version, else the scalar bool test (:1449).
-// Fixed order: first child (i+1) popped first.
+// (vecmath.h:1504) and the per-lane semantics of the packet version, else the scalar bool test (:1449).  Fixed order:
+// first child popped first.  maxT is constant, so testing a child when its parent is visited equals testing it at its pop.
+// Counting builds keep failed children on the stack so that a box test is counted exactly when the reference performs it
+// (children still on the stack when the ray is found occluded are never tested there).
 template <bool PACKET, bool COUNT>
 __device__ __forceinline__ bool occluded(const DevScene& sc, const DevRay& r, float maxT, const Stack& st, Traffic& tr, uint32_t& overflow)
 {
     DevHit dummy;
     for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        uint32_t cur = sc.root[m];
+        if (COUNT) tr.nBox++;
+        Box rb = root_box(sc, m);
+        if (!(PACKET ? box_soa(rb, r, maxT) : box_bool(rb, r, maxT))) continue;
+        uint32_t ref = sc.rootRef[m];
         int sp = 0;
         for (;;) {
-            Box nb;
-            uint32_t na, nf;
-            load_node(sc, cur, nb, na, nf);
-            if (COUNT) tr.nBox++;
-            bool h = PACKET ? box_soa(nb, r, maxT) : box_bool(nb, r, maxT);
-            if (h) {
-                if (nf & PRT_NODE_INTERNAL) {
-                    if (sp >= PRT_STACK_MAX - 1) { overflow = 1; break; }
-                    st.put(sp++, na);
-                    cur = cur + 1;
-                    continue;
+            bool descend = false;
+            if (ref == PRT_REF_DEAD) {
+                // counting build: a failed child, already counted at its pop
+            } else if (!(ref & PRT_REF_LEAF)) {
+                WideNode w;
+                load_wide(sc, ref, w);
+                bool h0 = PACKET ? box_soa(w.b0, r, maxT) : box_bool(w.b0, r, maxT);
+                bool h1 = PACKET ? box_soa(w.b1, r, maxT) : box_bool(w.b1, r, maxT);
+                if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; }
+                if (COUNT) {
+                    st.put(sp++, h1 ? w.ref1 : PRT_REF_DEAD);
+                    tr.nBox++; // child 0 is popped next
+                } else if (h1) {
+                    st.put(sp++, w.ref1);
                 }
-                if (leaf_intersect<true, PACKET, COUNT>(sc, na, nf, m, r, maxT, dummy, tr)) return true;
+                if (h0) {
+                    ref = w.ref0;
+                    descend = true;
+                }
+            } else {
+                if (leaf_intersect<true, PACKET, COUNT>(sc, ref, m, r, maxT, dummy, tr)) return true;
             }
+            if (descend) continue;
             if (sp == 0) break;
-            cur = st.get(--sp);
+            ref = st.get(--sp);
+            if (COUNT) tr.nBox++;
         }
     }
     return false;

@@ -122,10 +122,11 @@ struct RenderArgs {
 template <bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void render_kernel(RenderArgs A)
 {
-    __shared__ uint32_t ldsStack[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, slot = lane & 7u, gbase = lane & ~7u;
-    const Stack st{&ldsStack[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     const DevScene& sc = A.sc;
     const DevCamera& cam = A.cam;
     const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
@@ -368,9 +369,10 @@ struct RaysArgs {
 
 __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
 {
-    __shared__ uint32_t ldsStack[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, gbase = lane & ~7u;
-    const Stack st{&ldsStack[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     uint32_t i = blockIdx.x * PRT_BLOCK + tid;
     bool valid = i < A.n;
     uint32_t ii = valid ? i : 0;
@@ -626,7 +628,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     HIP_TRY(hipSetDevice(c->device));
     free_scene(c);
 
-    std::vector<float4> nodes, tris, shade, bump, mats, alpha;
+    std::vector<float4> wnodes, tris, shade, bump, mats, alpha;
     std::vector<uint4> texDesc;
     std::vector<uint8_t> texels;
     DevScene sc{};
@@ -651,9 +653,8 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         const prt_mesh_desc& md = s->meshes[m];
         if (!md.nodes || !md.primRemapping || !md.indices || !md.positions || !md.primMaterial || !md.materials || md.nodeCount == 0)
             return fail(PRT_HIP_EINVAL, "mesh descriptor has NULL arrays");
-        const uint32_t nodeBase = (uint32_t)(nodes.size() / 2), triBase = (uint32_t)(tris.size() / 3);
+        const uint32_t triBase = (uint32_t)(tris.size() / 3);
         const uint32_t primBase = (uint32_t)(shade.size() / 4), matBase = (uint32_t)(mats.size() / 3);
-        sc.root[m] = nodeBase;
         sc.primBase[m] = primBase;
         sc.hasNormals[m] = md.normals ? 1u : 0u;
         auto P = [&](uint32_t v) { return HVec3{md.positions[3 * v], md.positions[3 * v + 1], md.positions[3 * v + 2]}; };
@@ -666,21 +667,39 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             mats.push_back(make_float4(mt.emissive[0], mt.emissive[1], mt.emissive[2], ubits(mt.alphaTest)));
             mats.push_back(make_float4(ubits((uint32_t)mt.diffuseMap), ubits((uint32_t)mt.bumpMap), 0.0f, 0.0f));
         }
-        for (uint32_t i = 0; i < md.nodeCount; i++) {
-            const prt_bvh_node& n = md.nodes[i];
-            uint32_t a, b;
-            if (n.primCount == 0xf) {
-                if (n.primOrSecondNodeIndex >= md.nodeCount || i + 1 >= md.nodeCount) return fail(PRT_HIP_EINVAL, "bad child index");
-                a = nodeBase + n.primOrSecondNodeIndex;
-                b = PRT_NODE_INTERNAL | (n.splitAxis & 3u);
-            } else {
-                if (n.primCount == 0 || n.primCount > 8 || n.primOrSecondNodeIndex + n.primCount > md.primCount)
+        // Wide records: one per internal node, in the reference's DFS order.  wideIndex[i] = record of node i.
+        {
+            std::vector<uint32_t> wideIndex(md.nodeCount, 0);
+            uint32_t nextWide = (uint32_t)(wnodes.size() / 4);
+            for (uint32_t i = 0; i < md.nodeCount; i++) {
+                const prt_bvh_node& n = md.nodes[i];
+                if (n.primCount == 0xf) {
+                    if (n.primOrSecondNodeIndex >= md.nodeCount || n.primOrSecondNodeIndex <= i || i + 1 >= md.nodeCount)
+                        return fail(PRT_HIP_EINVAL, "bad child index");
+                    wideIndex[i] = nextWide++;
+                } else if (n.primCount == 0 || n.primCount > 8 || n.primOrSecondNodeIndex + n.primCount > md.primCount) {
                     return fail(PRT_HIP_EINVAL, "bad leaf range");
-                a = triBase + n.primOrSecondNodeIndex;
-                b = n.primCount;
+                }
             }
-            nodes.push_back(make_float4(n.lower[0], n.lower[1], n.lower[2], n.upper[0]));
-            nodes.push_back(make_float4(n.upper[1], n.upper[2], ubits(a), ubits(b)));
+            if ((size_t)triBase + md.primCount >= (1u << 27) || nextWide >= (1u << 30)) return fail(PRT_HIP_EINVAL, "scene too large for 32-bit child references");
+            auto refOf = [&](uint32_t i) -> uint32_t {
+                const prt_bvh_node& n = md.nodes[i];
+                if (n.primCount == 0xf) return wideIndex[i];
+                return PRT_REF_LEAF | ((triBase + n.primOrSecondNodeIndex) << 4) | n.primCount;
+            };
+            for (uint32_t i = 0; i < md.nodeCount; i++) {
+                const prt_bvh_node& n = md.nodes[i];
+                if (n.primCount != 0xf) continue;
+                const prt_bvh_node& c0 = md.nodes[i + 1];
+                const prt_bvh_node& c1 = md.nodes[n.primOrSecondNodeIndex];
+                wnodes.push_back(make_float4(c0.lower[0], c0.lower[1], c0.lower[2], c0.upper[0]));
+                wnodes.push_back(make_float4(c0.upper[1], c0.upper[2], c1.lower[0], c1.lower[1]));
+                wnodes.push_back(make_float4(c1.lower[2], c1.upper[0], c1.upper[1], c1.upper[2]));
+                wnodes.push_back(make_float4(ubits(refOf(i + 1)), ubits(refOf(n.primOrSecondNodeIndex)), ubits(n.splitAxis & 3u), 0.0f));
+            }
+            sc.rootRef[m] = refOf(0);
+            memcpy(&sc.rootBox[m][0], md.nodes[0].lower, 12);
+            memcpy(&sc.rootBox[m][3], md.nodes[0].upper, 12);
         }
         // leaf triangles in primRemapping order (TriangleVector, bvh.cpp:245-296)
         for (uint32_t k = 0; k < md.primCount; k++) {
@@ -747,7 +766,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     sc.radius = s->radius;
 
     int rc;
-    if ((rc = upload_vec(c, nodes, &sc.nodes))) return rc;
+    if ((rc = upload_vec(c, wnodes, &sc.wnodes))) return rc;
     if ((rc = upload_vec(c, tris, &sc.tris))) return rc;
     if ((rc = upload_vec(c, shade, &sc.shade))) return rc;
     if ((rc = upload_vec(c, bump, &sc.bump))) return rc;
@@ -776,7 +795,7 @@ static int ensure_launch_resources(prt_hip_ctx* c, uint32_t blocks)
     if (threads > c->spillThreads) {
         if (c->spill) (void)hipFree(c->spill);
         c->spill = nullptr;
-        HIP_TRY(hipMalloc(&c->spill, (size_t)threads * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->spill, (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
         c->spillThreads = threads;
     }
     return PRT_HIP_OK;
