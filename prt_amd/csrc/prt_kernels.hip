@@ -101,242 +101,364 @@ struct Surf5 { // what moves between slots at a compaction
     uint32_t mat, prim;
 };
 
-// ============================================================================ render kernel
-struct RenderArgs {
+// ============================================================================ wavefront pipeline
+// The per-pixel loop of the reference is run as a state machine over ALL pixel groups at once (DESIGN.md "Kernels"):
+//
+//   shade_kernel   8 lanes per pixel group (one lane per path slot).  Consumes the hits of the previous iteration
+//                  (gathering alive paths into slots 0..n-1 by ballot/prefix rank), runs the bounce phase of
+//                  path_tracer.cpp:124-293 (RNG draws by prefix-counted stepping of the shared xorshift state, BSDF
+//                  direction, Russian roulette) and EMITS the rays of the next iteration into per-mode queues, packed
+//                  by wave ballot + prefix sum + one atomic per wave.
+//   trace_kernel   one lane per queued ray, one instantiation per traversal mode (primary packet rays, scatter
+//                  rays, packet / single occlusion rays), results written back to the owner slot.
+//
+// One iteration = shade + 4 traces; a packet needs 1 + maxDepth iterations, so an image needs
+// (samples/8)*(1+maxDepth)+1 iterations, enqueued back to back without host synchronisation.
+enum { Q_PRIMARY = 0, Q_SCATTER = 1, Q_OCC_PACKET = 2, Q_OCC_SINGLE = 3, Q_COUNT = 4 };
+enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
+#define SLOT_HAS_SHADOW 1u
+#define SLOT_SURVIVE 2u
+
+struct WfArgs {
     DevScene sc;
     DevCamera cam;
     prt_render_params p;
     uint32_t x0, y0, x1, y1;
-    uint32_t tilesXImage;           // image width in tiles
-    uint32_t rtx0, rty0, rtnx, rtny; // tile range covering the rectangle
-    uint32_t fullWidth;             // rectangle spans whole image rows -> owned tiles are an arithmetic progression
-    uint32_t firstOwned, ownedCount;
-    uint32_t totalWork;             // ownedCount (or rect tiles) * tileSize^2
+    uint32_t tilesXImage;
+    uint32_t rtx0, rty0, rtnx, rtny;
+    uint32_t fullWidth, firstOwned;
+    uint32_t workBase;   // first work item (tile-major pixel index) of this pass
+    uint32_t groupCount; // pixel groups in this pass
     float* rgb;
-    uint32_t* work;                 // atomic work counter
-    unsigned long long* counters;   // rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
+    unsigned long long* counters; // rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
+    // per group
+    uint32_t* gRng;
+    uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20
+    uint32_t* gPixel; // x | y << 16, 0xffffffff = no pixel (outside the rectangle / not this rank's tile)
+    float4* gColor;
+    // per slot (8 per group)
+    float4 *S0, *S1, *S2, *S3, *S4, *S5, *S6;
+    float4* hitA;   // t i j k
+    uint2* hitB;    // primId meshId
+    uint32_t* occl; // 1 = occluded
+    // ray queues
+    float4* qA[Q_COUNT]; // org.xyz dir.x
+    float4* qB[Q_COUNT]; // dir.yz maxT bits(owner | reverseBits << 26)
+    uint32_t* qCount;    // Q_COUNT counters
     uint32_t* spill;
     uint32_t spillStride;
 };
 
-template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK) void render_kernel(RenderArgs A)
+// Append this lane's ray to queue q: ranks by wave ballot + popcount, one atomic per wave.
+__device__ __forceinline__ void emit_ray(const WfArgs& A, int q, bool want, Vec3 org, Vec3 dir, float maxT, uint32_t bits)
 {
-    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
-    __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&A.qCount[q], (uint32_t)__popcll(mask));
+    base = shu(base, leader);
+    if (want) {
+        uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        A.qA[q][idx] = make_float4(org.x, org.y, org.z, dir.x);
+        A.qB[q][idx] = make_float4(dir.y, dir.z, maxT, asf(bits));
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
+{
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, slot = lane & 7u, gbase = lane & ~7u;
-    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const uint32_t g = (blockIdx.x * PRT_BLOCK + tid) >> 3;
+    const bool inRange = g < A.groupCount; // whole groups are in or out together
+    const uint32_t gs = (inRange ? g : 0u) * 8u + slot;
     const DevScene& sc = A.sc;
     const DevCamera& cam = A.cam;
-    const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
-    const uint32_t samples = A.p.samples, maxDepth = A.p.maxDepth, rrDepth = A.p.rrDepth;
+    const uint32_t samples = A.p.samples, maxDepth = A.p.maxDepth, rrDepth = A.p.rrDepth, packets = samples / 8u;
     const float kPi = 3.14159265358979323846f;
-    const float kFar = 2.0f * sc.radius;   // path_tracer.cpp:192
-    const float kEpsilon = 0.0008f;        // :193
+    const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
+    const float kEpsilon = 0.0008f;      // :193
     const uint32_t lowerMask = (1u << slot) - 1u;
 
     Traffic tr{0, 0, 0, 0};
-    uint32_t overflow = 0;
     unsigned long long nRays = 0, nOccl = 0, nPx = 0;
 
-    for (;;) {
-        uint32_t w = 0;
-        if (slot == 0) w = atomicAdd(A.work, 1u);
-        w = shu(w, gbase);
-        if (w >= A.totalWork) break;
-        // work item -> pixel: tile-major, row-major inside a tile (main.cpp:132-138 tiles)
-        uint32_t tq = w / tile2, pix = w - tq * tile2;
-        uint32_t gt;
-        if (A.fullWidth) {
-            gt = A.firstOwned + tq * A.p.nranks;
+    uint32_t info = inRange ? A.gInfo[g] : ((uint32_t)PH_DONE << 20);
+    uint32_t phase = info >> 20, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
+    uint32_t rng = 0, pixel = 0xffffffffu;
+    Vec3 color = mk3(0, 0, 0);
+    if (phase != PH_DONE) {
+        rng = A.gRng[g];
+        pixel = A.gPixel[g];
+        float4 c = A.gColor[g];
+        color = mk3(c.x, c.y, c.z);
+    }
+    const uint32_t x = pixel & 0xffffu, y = pixel >> 16;
+
+    // slot state
+    Vec3 pos = mk3(0, 0, 0), rayDir = mk3(0, 0, 0), normal = mk3(0, 0, 0), beta = mk3(1, 1, 1), result = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
+    Surface props{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+    uint32_t material = 0, sflags = 0, lightSet = 0;
+
+    bool needBounce = false, needEnd = false, needCamera = false;
+    bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
+    Vec3 eOrg = mk3(0, 0, 0), eDir = mk3(0, 0, 0), sOrg = mk3(0, 0, 0), sDir = mk3(0, 0, 0);
+    uint32_t reverseBits = 0;
+
+    if (phase == PH_START) {
+        if (pixel == 0xffffffffu || packets == 0u) {
+            phase = PH_DONE;
+            if (pixel != 0xffffffffu && slot == 0) { // samples < 8: the reference still writes 0/samples
+                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
+                px[0] = px[1] = px[2] = A.p.exposure * (0.0f / (float)samples);
+                nPx++;
+                nRays += samples;
+            }
         } else {
-            uint32_t qx = tq % A.rtnx, qy = tq / A.rtnx;
-            gt = (A.rty0 + qy) * A.tilesXImage + (A.rtx0 + qx);
-            if (gt % A.p.nranks != A.p.rank) continue;
+            needCamera = true;
+            if (slot == 0) nRays += samples; // path_tracer.cpp:62
         }
-        uint32_t tx = gt % A.tilesXImage, ty = gt / A.tilesXImage;
-        uint32_t x = tx * tile + pix % tile, y = ty * tile + pix / tile;
-        if (x < A.x0 || x > A.x1 || y < A.y0 || y > A.y1) continue;
-
-        uint32_t rng = pixel_seed(x, y, cam.width, A.p.seed);
-        Vec3 color = mk3(0.0f, 0.0f, 0.0f);
-        if (slot == 0) nRays += samples; // path_tracer.cpp:62
-
-        for (uint32_t pk = 0; pk < samples / 8u; pk++) {
-            // ---- primary packet (camera.cpp:35-73, scene.cpp:47-63)
-            DevRay pr;
-            Vec3 avgDir;
-            camera_packet(cam, rng, x, y, slot, gbase, pr, avgDir);
-            uint32_t reverseBits = (avgDir.x < 0.0f ? 1u : 0u) | (avgDir.y < 0.0f ? 2u : 0u) | (avgDir.z < 0.0f ? 4u : 0u);
-            DevHit h;
-            intersect_packet<COUNT>(sc, pr, reverseBits, 100000.0f, h, st, tr, overflow);
-
-            // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
-            bool isHit = h.t != -1.0f;
-            Surf5 sv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-            Vec3 snormal = mk3(0, 0, 0), spos = mk3(0, 0, 0);
-            if (isHit) {
-                Surface s;
-                get_surface<COUNT>(sc, h, s, tr);
-                sv = Surf5{s.normal, s.uv, s.mat, s.prim};
-                snormal = sample_bump<COUNT>(sc, s.mat, s, tr);
-                spos = add3(scale3(h.t, pr.dir), pr.org);
+    } else if (phase == PH_WAIT_PRIMARY) {
+        // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
+        float4 ha = A.hitA[gs];
+        uint2 hb = A.hitB[gs];
+        float4 s6 = A.S6[gs]; // the primary ray's direction
+        Vec3 pdir = mk3(s6.x, s6.y, s6.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+        DevHit h{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
+        bool isHit = h.t != -1.0f;
+        Surf5 sv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+        Vec3 snormal = mk3(0, 0, 0), spos = mk3(0, 0, 0);
+        if (isHit) {
+            Surface s;
+            get_surface<COUNT>(sc, h, s, tr);
+            sv = Surf5{s.normal, s.uv, s.mat, s.prim};
+            snormal = sample_bump<COUNT>(sc, s.mat, s, tr);
+            spos = add3(scale3(h.t, pdir), porg);
+        }
+        uint32_t hm = group_ballot(isHit, gbase);
+        alive = __popc(hm);
+        uint32_t src = gbase + ((slot < alive) ? nth_set(hm, slot) : slot);
+        props.normal = sh3(sv.normal, src);
+        props.uv = Vec2{shf(sv.uv.x, src), shf(sv.uv.y, src)};
+        props.mat = shu(sv.mat, src);
+        props.prim = shu(sv.prim, src);
+        material = props.mat;
+        normal = sh3(snormal, src);
+        pos = sh3(spos, src);
+        rayDir = sh3(pdir, src);
+        beta = mk3(1.0f, 1.0f, 1.0f);
+        result = mk3(0.0f, 0.0f, 0.0f);
+        lightSet = 0;
+        depth = 0;
+        if (alive != 0u && depth < maxDepth) needBounce = true;
+        else needEnd = true;
+    } else if (phase == PH_WAIT_BOUNCE) {
+        float4 s0 = A.S0[gs], s1 = A.S1[gs], s2 = A.S2[gs], s3 = A.S3[gs], s4 = A.S4[gs], s5 = A.S5[gs], s6 = A.S6[gs];
+        pos = mk3(s0.x, s0.y, s0.z);
+        rayDir = mk3(s0.w, s1.x, s1.y);
+        normal = mk3(s1.z, s1.w, s2.x);
+        props.normal = mk3(s2.y, s2.z, s2.w);
+        props.uv = Vec2{s3.x, s3.y};
+        props.mat = asu(s3.z);
+        props.prim = asu(s3.w);
+        beta = mk3(s4.x, s4.y, s4.z);
+        material = asu(s4.w) & 0xffffffu;
+        lightSet = (asu(s4.w) >> 24) & 1u;
+        result = mk3(s5.x, s5.y, s5.z);
+        sflags = asu(s5.w);
+        ndir = mk3(s6.x, s6.y, s6.z);
+        // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
+        if (sflags & SLOT_HAS_SHADOW) {
+            if (A.occl[gs] == 0u) {
+                Vec3 lightDir = lightSet ? mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]) : mk3(0, 0, 0);
+                Vec3 lightInt = lightSet ? mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]) : mk3(0, 0, 0);
+                Vec3 lr = div3s(scale3(std_max(dot3(lightDir, normal), 0.0f), lightInt), kPi);
+                result = add3(result, mul3(beta, lr));
             }
-            uint32_t hm = group_ballot(isHit, gbase);
-            uint32_t alive = __popc(hm);
-            uint32_t src = gbase + ((slot < alive) ? nth_set(hm, slot) : slot);
-            Surface props;
-            props.normal = sh3(sv.normal, src);
-            props.uv = Vec2{shf(sv.uv.x, src), shf(sv.uv.y, src)};
-            props.mat = shu(sv.mat, src);
-            props.prim = shu(sv.prim, src);
-            uint32_t material = props.mat;
-            Vec3 normal = sh3(snormal, src);
-            Vec3 pos = sh3(spos, src);
-            Vec3 rayDir = sh3(pr.dir, src);
-            Vec3 beta = mk3(1.0f, 1.0f, 1.0f), result = mk3(0.0f, 0.0f, 0.0f);
-            Vec3 lightDir = mk3(0, 0, 0), lightInt = mk3(0, 0, 0);
-
-            uint32_t depth = 0;
-            while (alive != 0 && depth < maxDepth) { // path_tracer.cpp:124
-                const bool active = slot < alive;
-                uint32_t rtype = 2u;
-                float4 m0 = make_float4(0, 0, 0, 0), m1 = make_float4(0, 0, 0, 0);
-                if (active) {
-                    const float4* mp = sc.mats + 3 * (size_t)material;
-                    m0 = mp[0];
-                    m1 = mp[1];
-                    rtype = asu(m0.w);
-                    if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
-                }
-                // ---- two draws per diffuse/specular slot, in slot order (:142-144, :175-177)
-                const bool draws = active && (rtype == 0u || rtype == 1u);
-                uint32_t dm = group_ballot(draws, gbase);
-                uint32_t pre = 2u * __popc(dm & lowerMask), tot = 2u * __popc(dm);
-                uint32_t s = rng, r2b = 0, r1b = 0;
-                for (uint32_t j = 0; j < tot; j++) {
-                    s = xorshift32(s);
-                    if (j == pre) r2b = s;
-                    if (j == pre + 1u) r1b = s;
-                }
-                rng = s;
-                Vec3 nextDir = mk3(0, 0, 0);
-                bool wantLight = false;
-                if (draws) {
-                    Vec3 dd = diffuse_dir(normal, rng_to_float(r2b), rng_to_float(r1b));
-                    if (rtype == 0u) {
-                        nextDir = dd;
-                        beta = mul3(beta, sample_diffuse<COUNT>(sc, material, props.uv, tr)); // :162
-                        if (sc.hasLight) { // :168-172
-                            lightDir = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
-                            lightInt = mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]);
-                            wantLight = true;
-                        }
-                    } else {
-                        Vec3 reflectDir = sub3(rayDir, scale3(dot3(normal, rayDir), scale3(2.0f, normal))); // :186
-                        nextDir = add3(scale3(0.9f, reflectDir), scale3(0.1f, dd));
-                    }
-                }
-                // ---- occlusion rays (:196-252): packet traversal when more than 2 paths are alive
-                const bool directLighting = group_ballot(wantLight, gbase) != 0u;
-                if (directLighting && active) {
-                    const bool grouping = (alive & 0xfu) > 2u;
-                    DevRay sr;
-                    sr.org = add3(pos, scale3(kFar, lightDir));
-                    sr.dir = mk3(-lightDir.x, -lightDir.y, -lightDir.z);
-                    nRays++;
-                    nOccl++;
-                    bool occ;
-                    if (grouping) {
-                        prepare_soa(sr);
-                        occ = occluded<true, COUNT>(sc, sr, kFar - kEpsilon, st, tr, overflow);
-                    } else {
-                        prepare_single(sr);
-                        occ = occluded<false, COUNT>(sc, sr, kFar - kEpsilon, st, tr, overflow);
-                    }
-                    if (!occ) {
-                        Vec3 lr = div3s(scale3(std_max(dot3(lightDir, normal), 0.0f), lightInt), kPi); // :229, :247
-                        result = add3(result, mul3(beta, lr));
-                    }
-                }
-                // ---- Russian roulette: one draw per alive slot in slot order when depth > rrDepth (:258-265)
-                bool survive = active;
-                Vec3 betaNew = beta;
-                if (depth > rrDepth) {
-                    uint32_t s2 = rng, ub = 0;
-                    for (uint32_t j = 0; j < alive; j++) {
-                        s2 = xorshift32(s2);
-                        if (j == slot) ub = s2;
-                    }
-                    rng = s2;
-                    if (active) {
-                        float q = std_max(0.05f, 1.0f - length3(beta));
-                        if (rng_to_float(ub) < q) survive = false;
-                        else betaNew = div3s(beta, 1.0f - q);
-                    }
-                }
-                // ---- scatter ray (:267-293)
-                bool hitNext = false;
-                Surf5 nv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-                Vec3 npos = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
-                Surface ns;
-                if (survive) {
-                    ndir = normalize3(nextDir);
-                    DevRay rr;
-                    rr.org = pos;
-                    rr.dir = ndir;
-                    prepare_single(rr);
-                    nRays++;
-                    DevHit nh;
-                    intersect_single<COUNT>(sc, rr, kFar, nh, st, tr, overflow);
-                    if (nh.t != -1.0f) {
-                        hitNext = true;
-                        get_surface<COUNT>(sc, nh, ns, tr);
-                        npos = add3(scale3(nh.t, ndir), pos);
-                    }
-                }
-                // ---- ordered compaction into slot ci (:283-291)
-                uint32_t nm = group_ballot(hitNext, gbase);
-                uint32_t nAlive = __popc(nm);
-                if (nAlive == 0u) break; // :295
-                uint32_t ci = __popc(nm & lowerMask);
-                uint32_t smat = 0;
-                Vec3 snorm = mk3(0, 0, 0);
-                if (hitNext) {
-                    // materials[ci] = props[i].material reads the slot's PREVIOUS surface unless ci == i (:286-288)
-                    smat = (ci == slot) ? ns.mat : props.mat;
-                    snorm = sample_bump<COUNT>(sc, smat, ns, tr);
-                    nv = Surf5{ns.normal, ns.uv, ns.mat, ns.prim};
-                }
-                uint32_t src2 = gbase + ((slot < nAlive) ? nth_set(nm, slot) : slot);
-                props.normal = sh3(nv.normal, src2);
-                props.uv = Vec2{shf(nv.uv.x, src2), shf(nv.uv.y, src2)};
-                props.mat = shu(nv.mat, src2);
-                props.prim = shu(nv.prim, src2);
-                material = shu(smat, src2);
-                normal = sh3(snorm, src2);
-                pos = sh3(npos, src2);
-                rayDir = sh3(ndir, src2);
-                Vec3 bmoved = sh3(betaNew, src2);
-                if (depth > rrDepth && slot < nAlive) beta = bmoved; // beta[ci] is only written under RR (:263)
-                alive = nAlive;
-                depth++;
+        }
+        // ---- scatter hits, ordered compaction into slot ci (path_tracer.cpp:281-293)
+        bool hitNext = false;
+        Surface ns{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+        Vec3 npos = mk3(0, 0, 0);
+        if (sflags & SLOT_SURVIVE) {
+            float4 ha = A.hitA[gs];
+            uint2 hb = A.hitB[gs];
+            DevHit nh{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
+            if (nh.t != -1.0f) {
+                hitNext = true;
+                get_surface<COUNT>(sc, nh, ns, tr);
+                npos = add3(scale3(nh.t, ndir), pos);
             }
-            // ---- Σ result[0..7] in slot order (:303-307), then color += (:71)
-            Vec3 res = mk3(0.0f, 0.0f, 0.0f);
+        }
+        uint32_t nm = group_ballot(hitNext, gbase);
+        uint32_t nAlive = __popc(nm);
+        if (nAlive == 0u) {
+            needEnd = true; // path_tracer.cpp:295
+        } else {
+            uint32_t ci = __popc(nm & lowerMask);
+            uint32_t smat = 0;
+            Vec3 snorm = mk3(0, 0, 0);
+            Surf5 nv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+            if (hitNext) {
+                // materials[ci] = props[i].material reads the slot's PREVIOUS surface unless ci == i (:286-288)
+                smat = (ci == slot) ? ns.mat : props.mat;
+                snorm = sample_bump<COUNT>(sc, smat, ns, tr);
+                nv = Surf5{ns.normal, ns.uv, ns.mat, ns.prim};
+            }
+            // beta[ci] = beta[i]/(1-q) is only written under Russian roulette (:263); q is a function of beta
+            Vec3 betaNew = beta;
+            if (depth > rrDepth) {
+                float q = std_max(0.05f, 1.0f - length3(beta));
+                betaNew = div3s(beta, 1.0f - q);
+            }
+            uint32_t src2 = gbase + ((slot < nAlive) ? nth_set(nm, slot) : slot);
+            props.normal = sh3(nv.normal, src2);
+            props.uv = Vec2{shf(nv.uv.x, src2), shf(nv.uv.y, src2)};
+            props.mat = shu(nv.mat, src2);
+            props.prim = shu(nv.prim, src2);
+            material = shu(smat, src2);
+            normal = sh3(snorm, src2);
+            pos = sh3(npos, src2);
+            rayDir = sh3(ndir, src2);
+            Vec3 bmoved = sh3(betaNew, src2);
+            if (depth > rrDepth && slot < nAlive) beta = bmoved;
+            alive = nAlive;
+            depth++;
+            if (depth < maxDepth) needBounce = true;
+            else needEnd = true;
+        }
+    }
+
+    if (needBounce) {
+        // ---- one bounce (path_tracer.cpp:131-190 and the Russian roulette of :258-265)
+        const bool active = slot < alive;
+        uint32_t rtype = 2u;
+        if (active) {
+            const float4* mp = sc.mats + 3 * (size_t)material;
+            float4 m0 = mp[0], m1 = mp[1];
+            rtype = asu(m0.w);
+            if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
+        }
+        const bool draws = active && (rtype == 0u || rtype == 1u);
+        uint32_t dm = group_ballot(draws, gbase);
+        uint32_t pre = 2u * __popc(dm & lowerMask), tot = 2u * __popc(dm);
+        uint32_t s = rng, r2b = 0, r1b = 0;
+        for (uint32_t j = 0; j < tot; j++) {
+            s = xorshift32(s);
+            if (j == pre) r2b = s;
+            if (j == pre + 1u) r1b = s;
+        }
+        rng = s;
+        Vec3 nextDir = mk3(0, 0, 0);
+        bool wantLight = false;
+        if (draws) {
+            Vec3 dd = diffuse_dir(normal, rng_to_float(r2b), rng_to_float(r1b));
+            if (rtype == 0u) {
+                nextDir = dd;
+                beta = mul3(beta, sample_diffuse<COUNT>(sc, material, props.uv, tr)); // :162
+                if (sc.hasLight) { // :168-172
+                    lightSet = 1u;
+                    wantLight = true;
+                }
+            } else {
+                Vec3 reflectDir = sub3(rayDir, scale3(dot3(normal, rayDir), scale3(2.0f, normal))); // :186
+                nextDir = add3(scale3(0.9f, reflectDir), scale3(0.1f, dd));
+            }
+        }
+        const bool directLighting = group_ballot(wantLight, gbase) != 0u;
+        sflags = 0;
+        if (directLighting && active) { // :196-252: every alive path gets an occlusion ray
+            Vec3 lightDir = lightSet ? mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]) : mk3(0, 0, 0);
+            sOrg = add3(pos, scale3(kFar, lightDir));
+            sDir = mk3(-lightDir.x, -lightDir.y, -lightDir.z);
+            emitShadow = true;
+            shadowPacket = (alive & 0xfu) > 2u; // :198
+            sflags |= SLOT_HAS_SHADOW;
+            nRays++;
+            nOccl++;
+        }
+        bool survive = active;
+        if (depth > rrDepth) { // one draw per alive slot, in slot order
+            uint32_t s2 = rng, ub = 0;
+            for (uint32_t j = 0; j < alive; j++) {
+                s2 = xorshift32(s2);
+                if (j == slot) ub = s2;
+            }
+            rng = s2;
+            if (active) {
+                float q = std_max(0.05f, 1.0f - length3(beta));
+                if (rng_to_float(ub) < q) survive = false;
+            }
+        }
+        if (survive) {
+            ndir = normalize3(nextDir); // :267
+            eOrg = pos;
+            eDir = ndir;
+            emitScatter = true;
+            sflags |= SLOT_SURVIVE;
+            nRays++;
+        }
+        phase = PH_WAIT_BOUNCE;
+    }
+
+    if (needEnd) {
+        // ---- Σ result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71)
+        Vec3 res = mk3(0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (uint32_t l = 0; l < 8; l++) res = add3(res, sh3(result, gbase + l));
-            color = add3(color, res);
+        for (uint32_t l = 0; l < 8; l++) res = add3(res, sh3(result, gbase + l));
+        color = add3(color, res);
+        pk++;
+        if (pk < packets) {
+            needCamera = true;
+        } else {
+            Vec3 c = scale3(A.p.exposure, div3s(color, (float)samples)); // path_tracer.cpp:28, image.cpp:45
+            if (slot == 0) {
+                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
+                px[0] = c.x;
+                px[1] = c.y;
+                px[2] = c.z;
+                nPx++;
+            }
+            phase = PH_DONE;
         }
-        color = div3s(color, (float)samples);       // path_tracer.cpp:28
-        Vec3 c = scale3(A.p.exposure, color);       // image.cpp:45
+    }
+
+    if (needCamera) {
+        DevRay pr;
+        Vec3 avgDir;
+        camera_packet(cam, rng, x, y, slot, gbase, pr, avgDir);
+        reverseBits = (avgDir.x < 0.0f ? 1u : 0u) | (avgDir.y < 0.0f ? 2u : 0u) | (avgDir.z < 0.0f ? 4u : 0u);
+        eOrg = pr.org;
+        eDir = pr.dir;
+        ndir = pr.dir;
+        emitPrimary = true;
+        phase = PH_WAIT_PRIMARY;
+    }
+
+    // ---- converged part: pack the rays of the next iteration into the queues
+    const uint32_t owner = gs;
+    emit_ray(A, Q_PRIMARY, emitPrimary, eOrg, eDir, 100000.0f, owner | (reverseBits << 26));
+    emit_ray(A, Q_SCATTER, emitScatter, eOrg, eDir, kFar, owner);
+    emit_ray(A, Q_OCC_PACKET, emitShadow && shadowPacket, sOrg, sDir, kFar - kEpsilon, owner);
+    emit_ray(A, Q_OCC_SINGLE, emitShadow && !shadowPacket, sOrg, sDir, kFar - kEpsilon, owner);
+
+    // ---- store state
+    if (inRange && (info >> 20) != PH_DONE) {
+        if (phase == PH_WAIT_BOUNCE) {
+            A.S0[gs] = make_float4(pos.x, pos.y, pos.z, rayDir.x);
+            A.S1[gs] = make_float4(rayDir.y, rayDir.z, normal.x, normal.y);
+            A.S2[gs] = make_float4(normal.z, props.normal.x, props.normal.y, props.normal.z);
+            A.S3[gs] = make_float4(props.uv.x, props.uv.y, asf(props.mat), asf(props.prim));
+            A.S4[gs] = make_float4(beta.x, beta.y, beta.z, asf((material & 0xffffffu) | (lightSet << 24)));
+            A.S5[gs] = make_float4(result.x, result.y, result.z, asf(sflags));
+        }
+        if (phase == PH_WAIT_BOUNCE || phase == PH_WAIT_PRIMARY) A.S6[gs] = make_float4(ndir.x, ndir.y, ndir.z, 0.0f);
         if (slot == 0) {
-            float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
-            px[0] = c.x;
-            px[1] = c.y;
-            px[2] = c.z;
-            nPx++;
+            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20);
+            A.gRng[g] = rng;
+            A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
         }
     }
     // ---- statistics
@@ -344,12 +466,86 @@ __global__ __launch_bounds__(PRT_BLOCK) void render_kernel(RenderArgs A)
     if (nRays) atomicAdd(&C[0], nRays);
     if (nOccl) atomicAdd(&C[1], nOccl);
     if (COUNT) {
-        if (tr.nBox) atomicAdd(&C[2], (unsigned long long)tr.nBox);
-        if (tr.nTri) atomicAdd(&C[3], (unsigned long long)tr.nTri);
         if (tr.nHit) atomicAdd(&C[4], (unsigned long long)tr.nHit);
         if (tr.nTap) atomicAdd(&C[5], (unsigned long long)tr.nTap);
     }
     if (nPx) atomicAdd(&C[6], nPx);
+}
+
+// Assigns pixels to the groups of a pass (tile-major order, row-major inside a 16x16 tile, main.cpp:132-138) and
+// seeds their generators (the build's per-pixel state, replacing random.h:15-17).
+__global__ void init_groups_kernel(WfArgs A)
+{
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.groupCount) return;
+    const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
+    uint32_t w = A.workBase + g;
+    uint32_t tq = w / tile2, pix = w - tq * tile2;
+    uint32_t gt;
+    bool ok = true;
+    if (A.fullWidth) {
+        gt = A.firstOwned + tq * A.p.nranks;
+    } else {
+        uint32_t qx = tq % A.rtnx, qy = tq / A.rtnx;
+        gt = (A.rty0 + qy) * A.tilesXImage + (A.rtx0 + qx);
+        ok = (gt % A.p.nranks) == A.p.rank;
+    }
+    uint32_t tx = gt % A.tilesXImage, ty = gt / A.tilesXImage;
+    uint32_t x = tx * tile + pix % tile, y = ty * tile + pix / tile;
+    if (x < A.x0 || x > A.x1 || y < A.y0 || y > A.y1) ok = false;
+    A.gPixel[g] = ok ? (x | (y << 16)) : 0xffffffffu;
+    A.gRng[g] = ok ? pixel_seed(x, y, A.cam.width, A.p.seed) : 0u;
+    A.gInfo[g] = (uint32_t)PH_START << 20;
+    A.gColor[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// One lane per queued ray.  MODE: Q_PRIMARY packet-nearest, Q_SCATTER single-nearest, Q_OCC_PACKET / Q_OCC_SINGLE any-hit.
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
+{
+    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ float ldsT[(MODE == Q_PRIMARY ? PRT_STACK_LDS : 1) * PRT_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const uint32_t n = A.qCount[MODE];
+    Traffic tr{0, 0, 0, 0};
+    uint32_t overflow = 0;
+    for (uint32_t i = blockIdx.x * PRT_BLOCK + tid; i < n; i += gridDim.x * PRT_BLOCK) {
+        float4 ra = A.qA[MODE][i], rb = A.qB[MODE][i];
+        DevRay r;
+        r.org = mk3(ra.x, ra.y, ra.z);
+        r.dir = mk3(ra.w, rb.x, rb.y);
+        const float maxT = rb.z;
+        const uint32_t bits = asu(rb.w), owner = bits & 0x3ffffffu;
+        if (MODE == Q_PRIMARY || MODE == Q_SCATTER) {
+            DevHit h;
+            if (MODE == Q_PRIMARY) {
+                prepare_soa(r);
+                intersect_packet<COUNT>(A.sc, r, bits >> 26, maxT, h, st, tr, overflow);
+            } else {
+                prepare_single(r);
+                intersect_single<COUNT>(A.sc, r, maxT, h, st, tr, overflow);
+            }
+            A.hitA[owner] = make_float4(h.t, h.i, h.j, h.k);
+            A.hitB[owner] = make_uint2(h.primId, h.meshId);
+        } else {
+            bool occ;
+            if (MODE == Q_OCC_PACKET) {
+                prepare_soa(r);
+                occ = occluded<true, COUNT>(A.sc, r, maxT, st, tr, overflow);
+            } else {
+                prepare_single(r);
+                occ = occluded<false, COUNT>(A.sc, r, maxT, st, tr, overflow);
+            }
+            A.occl[owner] = occ ? 1u : 0u;
+        }
+    }
+    unsigned long long* C = A.counters;
+    if (COUNT) {
+        if (tr.nBox) atomicAdd(&C[2], (unsigned long long)tr.nBox);
+        if (tr.nTri) atomicAdd(&C[3], (unsigned long long)tr.nTri);
+        if (tr.nTap) atomicAdd(&C[5], (unsigned long long)tr.nTap);
+    }
     if (overflow) atomicAdd(&C[7], 1ull);
 }
 
@@ -531,8 +727,11 @@ struct prt_hip_ctx {
     // render resources
     float* fb = nullptr;
     size_t fbPixels = 0;
-    uint32_t* work = nullptr;
+    uint32_t* work = nullptr; // Q_COUNT queue counters
     unsigned long long* counters = nullptr;
+    void* wfBuffer = nullptr; // wavefront state + queues of one pass
+    size_t wfBytes = 0;
+    uint32_t wfGroups = 0;
     uint32_t* spill = nullptr;
     uint32_t spillThreads = 0;
     int blocksPerCU = 0;
@@ -549,6 +748,17 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
     if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T*)d;
     return PRT_HIP_OK;
+}
+
+template <bool COUNT>
+static void wf_iteration(const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
+{
+    (void)hipMemsetAsync(A.qCount, 0, Q_COUNT * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(shadeBlocks), dim3(PRT_BLOCK), 0, s, A);
+    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
+    hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
 }
 
 extern "C" {
@@ -578,6 +788,7 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipMalloc(&c->work, 256));
+    HIP_TRY(hipMemset(c->work, 0, 256));
     HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
     *out = c;
@@ -601,6 +812,7 @@ void prt_hip_destroy(prt_hip_ctx* c)
     if (c->work) (void)hipFree(c->work);
     if (c->counters) (void)hipFree(c->counters);
     if (c->spill) (void)hipFree(c->spill);
+    if (c->wfBuffer) (void)hipFree(c->wfBuffer);
     for (auto& e : c->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -805,10 +1017,44 @@ static int persistent_blocks(prt_hip_ctx* c)
 {
     if (c->blocksPerCU == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<Q_SCATTER, false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 2;
         c->blocksPerCU = std::min(nb, 8);
     }
     return c->computeUnits * c->blocksPerCU;
+}
+
+// Carves the wavefront state of `groups` pixel groups out of one allocation.
+static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
+{
+    const size_t slots = (size_t)groups * 8;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t need = 0;
+    need += 3 * al(groups * sizeof(uint32_t)) + al(groups * sizeof(float4));
+    need += 7 * al(slots * sizeof(float4)) + al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t));
+    need += 2 * Q_COUNT * al(slots * sizeof(float4));
+    if (need > c->wfBytes) {
+        if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+        c->wfBuffer = nullptr;
+        c->wfBytes = 0;
+        HIP_TRY(hipMalloc(&c->wfBuffer, need));
+        c->wfBytes = need;
+    }
+    char* p = (char*)c->wfBuffer;
+    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return r; };
+    A.gRng = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gInfo = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gPixel = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gColor = (float4*)take(groups * sizeof(float4));
+    float4** S[7] = {&A.S0, &A.S1, &A.S2, &A.S3, &A.S4, &A.S5, &A.S6};
+    for (auto ptr : S) *ptr = (float4*)take(slots * sizeof(float4));
+    A.hitA = (float4*)take(slots * sizeof(float4));
+    A.hitB = (uint2*)take(slots * sizeof(uint2));
+    A.occl = (uint32_t*)take(slots * sizeof(uint32_t));
+    for (int q = 0; q < Q_COUNT; q++) {
+        A.qA[q] = (float4*)take(slots * sizeof(float4));
+        A.qB[q] = (float4*)take(slots * sizeof(float4));
+    }
+    return PRT_HIP_OK;
 }
 
 int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const prt_render_params* p, float* d_rgb,
@@ -819,6 +1065,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     const uint32_t W = c->cam.width, H = c->cam.height;
     if (x1 < x0 || y1 < y0 || x1 >= W || y1 >= H) return fail(PRT_HIP_EINVAL, "pixel rectangle outside the image");
     if (p->samples == 0 || p->tileSize == 0 || p->nranks == 0 || p->rank >= p->nranks) return fail(PRT_HIP_EINVAL, "bad render params");
+    if (W > 65535 || H > 65535 || p->samples / 8 > 255 || p->maxDepth > 255) return fail(PRT_HIP_EINVAL, "image, sample count or depth too large");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     if (!d_rgb) {
@@ -831,7 +1078,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         }
         d_rgb = c->fb;
     }
-    RenderArgs A{};
+    WfArgs A{};
     A.sc = c->sc;
     A.cam = c->cam;
     A.p = *p;
@@ -842,28 +1089,31 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     A.rtnx = x1 / T - A.rtx0 + 1;
     A.rtny = y1 / T - A.rty0 + 1;
     A.fullWidth = (x0 == 0 && x1 == W - 1) ? 1u : 0u;
-    uint32_t tilesInRect = A.rtnx * A.rtny;
+    const uint32_t tilesInRect = A.rtnx * A.rtny;
+    uint64_t totalWork;
     if (A.fullWidth) {
         // tile ids rty0*TX .. (rty0+rtny)*TX - 1 are contiguous; this rank owns ids == rank (mod nranks)
         uint32_t lo = A.rty0 * A.tilesXImage, hi = lo + tilesInRect;
         uint32_t first = lo + ((p->rank + p->nranks - lo % p->nranks) % p->nranks);
         A.firstOwned = first;
-        A.ownedCount = first < hi ? (hi - first + p->nranks - 1) / p->nranks : 0;
-        A.totalWork = A.ownedCount * T * T;
+        uint32_t owned = first < hi ? (hi - first + p->nranks - 1) / p->nranks : 0;
+        totalWork = (uint64_t)owned * T * T;
     } else {
-        A.totalWork = tilesInRect * T * T;
+        totalWork = (uint64_t)tilesInRect * T * T;
     }
+    if (totalWork > 0xffffffffull) return fail(PRT_HIP_EINVAL, "rectangle too large");
     A.rgb = d_rgb;
-    A.work = c->work;
+    A.qCount = c->work;
     A.counters = c->counters;
-    uint32_t blocks = (uint32_t)persistent_blocks(c);
-    uint32_t needed = (A.totalWork * 8 + PRT_BLOCK - 1) / PRT_BLOCK;
-    blocks = std::max(1u, std::min(blocks, needed));
-    int rc = ensure_launch_resources(c, blocks);
+    const uint32_t traceBlocks = (uint32_t)persistent_blocks(c);
+    int rc = ensure_launch_resources(c, traceBlocks);
     if (rc) return rc;
     A.spill = c->spill;
     A.spillStride = c->spillThreads;
-    HIP_TRY(hipMemsetAsync(c->work, 0, sizeof(uint32_t), s));
+    const uint32_t kMaxGroupsPerPass = 4u << 20; // 2^26 slot references fit the 26-bit owner field of a queued ray
+    const uint32_t passGroups = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(totalWork, 1), kMaxGroupsPerPass);
+    if ((rc = wf_layout(c, passGroups, A))) return rc;
+
     HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), s));
     if (c->eventsUsed == c->events.size()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -874,10 +1124,19 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     hipEvent_t ev0 = c->events[c->eventsUsed].first, ev1 = c->events[c->eventsUsed].second;
     c->eventsUsed++;
     HIP_TRY(hipEventRecord(ev0, s));
-    if (p->countTraffic) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
+    const uint32_t iterations = (p->samples / 8) * (1 + p->maxDepth) + 1;
+    for (uint64_t base = 0; base < totalWork; base += passGroups) {
+        A.workBase = (uint32_t)base;
+        A.groupCount = (uint32_t)std::min<uint64_t>(passGroups, totalWork - base);
+        hipLaunchKernelGGL(init_groups_kernel, dim3((A.groupCount + 255) / 256), dim3(256), 0, s, A);
+        const uint32_t shadeBlocks = (uint32_t)(((uint64_t)A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
+        for (uint32_t it = 0; it < iterations; it++) {
+            if (p->countTraffic) wf_iteration<true>(A, shadeBlocks, traceBlocks, s);
+            else wf_iteration<false>(A, shadeBlocks, traceBlocks, s);
+        }
+    }
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("render_kernel launch: ") + hipGetErrorString(le));
+    if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("wavefront launch: ") + hipGetErrorString(le));
     HIP_TRY(hipEventRecord(ev1, s));
     c->timed = true;
     return PRT_HIP_OK;
