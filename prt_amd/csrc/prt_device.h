@@ -404,156 +404,231 @@ __device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t ref,
     return false;
 }
 
-// Scene::intersect<SingleRayHitPacket,SingleRayPacket> (scene.cpp:47-63) over Bvh::intersect single branch
-// (bvh.cpp:429-570, SORT_CHILDREN): root bool test, both children tested per internal node against the current
-// hit.t, near child first (t0 < t1, ties -> second child), popped nodes NOT re-tested (bvh.cpp:474).
-template <bool COUNT>
-__device__ __forceinline__ void intersect_single(const DevScene& sc, const DevRay& r, float maxT, DevHit& hit, const Stack& st,
-                                                 Traffic& tr, uint32_t& overflow)
+// ---------------------------------------------------------------------------- the four traversals as ONE stepper
+// MODE 0  Scene::intersect<RayHitPacket,RayPacket> for one lane of a packet (scene.cpp:47-63, bvh.cpp:429-570 packet branch)
+// MODE 1  Scene::intersect<SingleRayHitPacket,SingleRayPacket>               (bvh.cpp:429-570 single branch, SORT_CHILDREN)
+// MODE 2  Scene::occluded<RayPacketMask,RayPacket> for one lane              (scene.cpp:69-94, bvh.cpp:576-654)
+// MODE 3  Scene::occluded<bool,SingleRayPacket>
+//
+// What the reference's semantics fix, per mode:
+//  0: a node's box is tested when it is POPPED, against the hit.t of that moment (max_t0 < hit.t && min_t1 >= max_t0,
+//     vecmath.h:1504-1518); child order from sign(avgDir[splitAxis]) (bvh.cpp:523-529).  The reference walks 8 rays
+//     with a lane mask; every mask/hit update is lane-wise and the order is shared, so a lane walking alone over the
+//     nodes where its own mask bit is set sees the same nodes in the same order with the same hit.t.  Here the slab
+//     distances are computed when the PARENT is visited (its record holds the child boxes), max_t0 travels on the
+//     stack and the hit.t part of the test is redone at the pop -- the same decision.
+//  1: root bool test (vecmath.h:1449); both children tested per internal node against the current hit.t
+//     (vecmath.h:1402), near child first (t0 < t1, ties -> second child first), popped nodes NOT re-tested (bvh.cpp:474).
+//  2/3: any-hit, fixed order (first child popped first); maxT is constant, so testing a child at its parent equals
+//     testing it at its pop.  Counting builds keep failed children on the stack (PRT_REF_DEAD) so that a box test is
+//     counted exactly when the reference performs it (children still stacked when the ray is found occluded never are).
+#define PRT_MODE_PACKET 0
+#define PRT_MODE_SINGLE 1
+#define PRT_MODE_OCC_PACKET 2
+#define PRT_MODE_OCC_SINGLE 3
+#define PRT_REF_NONE 0xfffffffeu // no current node: start the next BVH or finish (never a valid leaf reference: count <= 8)
+
+struct Tracer {
+    DevRay r;
+    float maxT;
+    DevHit hit;
+    uint32_t ref;
+    int sp;
+    uint32_t m;   // current BVH; 0xffffffff before the first
+    uint32_t rev; // packet mode: sign bits of avgDir
+    bool occ;
+};
+
+template <int MODE>
+__device__ __forceinline__ void tracer_begin(Tracer& T, Vec3 org, Vec3 dir, float maxT, uint32_t rev)
 {
-    hit.t = maxT;
-    hit.i = hit.j = hit.k = 0.0f;
-    hit.primId = 0;
-    hit.meshId = 0;
-    for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        if (COUNT) tr.nBox++;
-        if (!box_bool(root_box(sc, m), r, hit.t)) continue;
-        uint32_t ref = sc.rootRef[m];
-        int sp = 0;
-        for (;;) {
-            if (!(ref & PRT_REF_LEAF)) {
-                WideNode w;
-                load_wide(sc, ref, w);
-                if (COUNT) tr.nBox += 2;
-                float t0 = box_t(w.b0, r), t1 = box_t(w.b1, r);
-                bool h0 = t0 < hit.t, h1 = t1 < hit.t;
-                if (h0 && h1) {
-                    if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; } // bvh.cpp:552
-                    bool near0 = t0 < t1;
-                    st.put(sp++, near0 ? w.ref1 : w.ref0);
-                    ref = near0 ? w.ref0 : w.ref1;
-                    continue;
-                } else if (h0) {
-                    ref = w.ref0;
-                    continue;
-                } else if (h1) {
-                    ref = w.ref1;
-                    continue;
-                }
-            } else {
-                leaf_intersect<false, false, COUNT>(sc, ref, m, r, hit.t, hit, tr);
-            }
-            if (sp == 0) break;
-            ref = st.get(--sp);
-        }
-    }
-    if (hit.t == maxT) hit.t = -1.0f;
+    T.r.org = org;
+    T.r.dir = dir;
+    if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET) prepare_soa(T.r);
+    else prepare_single(T.r);
+    T.maxT = maxT;
+    T.hit.t = maxT; // Scene::intersect: memset + setMaxT (scene.cpp:50-53)
+    T.hit.i = T.hit.j = T.hit.k = 0.0f;
+    T.hit.primId = 0;
+    T.hit.meshId = 0;
+    T.ref = PRT_REF_NONE;
+    T.sp = 0;
+    T.m = 0xffffffffu;
+    T.rev = rev;
+    T.occ = false;
 }
 
-// Scene::intersect<RayHitPacket,RayPacket> for ONE lane of the packet.  The reference walks the 8 rays together with
-// a per-entry lane mask (bvh.cpp:463-569); every mask and hit update is lane-wise and the visit order depends only on
-// sign(avgDir[splitAxis]) (:523-529), so a lane walking alone over the nodes where its own mask bit is set sees the same
-// nodes in the same order with the same hit.t.  The reference tests a node's box when it is POPPED, against the hit.t
-// of that moment (max_t0 < hit.t && min_t1 >= max_t0, vecmath.h:1504-1518); here the slab distances are computed when
-// the parent is visited (its record holds the child boxes), max_t0 travels on the stack, and the hit.t part of the test
-// is redone at the pop -- the same decision, since max_t0/min_t1 do not depend on hit.t.
-template <bool COUNT>
-__device__ __forceinline__ void intersect_packet(const DevScene& sc, const DevRay& r, uint32_t reverseBits, float maxT, DevHit& hit,
-                                                 const Stack& st, Traffic& tr, uint32_t& overflow)
+template <int MODE, bool COUNT>
+__device__ __forceinline__ uint32_t tracer_pop(Tracer& T, const Stack& st, Traffic& tr)
 {
-    hit.t = maxT;
-    hit.i = hit.j = hit.k = 0.0f;
-    hit.primId = 0;
-    hit.meshId = 0;
-    const float inf = __builtin_inff();
-    for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        if (COUNT) tr.nBox++;
-        if (!box_soa(root_box(sc, m), r, hit.t)) continue;
-        uint32_t ref = sc.rootRef[m];
-        int sp = 0;
-        for (;;) {
-            bool descend = false;
-            if (!(ref & PRT_REF_LEAF)) {
-                WideNode w;
-                load_wide(sc, ref, w);
-                if (COUNT) tr.nBox += 2; // both children are popped and tested by the reference
-                float e0 = box_soa_entry(w.b0, r), e1 = box_soa_entry(w.b1, r); // max_t0, or +inf when min_t1 < max_t0
-                if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; }
-                // popped first = top of stack: the second child unless reverse (bvh.cpp:523-529)
-                bool rev = (reverseBits >> (w.axis & 3u)) & 1u;
-                uint32_t firstRef = rev ? w.ref1 : w.ref0, laterRef = rev ? w.ref0 : w.ref1;
-                float firstE = rev ? e1 : e0, laterE = rev ? e0 : e1;
-                if (laterE < hit.t) st.putT(sp++, laterRef, laterE); // hit.t only shrinks: failing now means failing at the pop
-                if (firstE < hit.t) {
-                    ref = firstRef;
-                    descend = true;
-                }
-            } else {
-                leaf_intersect<false, true, COUNT>(sc, ref, m, r, hit.t, hit, tr);
-            }
-            if (descend) continue;
-            bool found = false;
-            while (sp > 0) {
-                --sp;
-                float e = st.getT(sp);
-                if (e < hit.t) { // the pop-time test of the reference
-                    ref = st.get(sp);
-                    found = true;
-                    break;
-                }
-            }
-            if (!found) break;
+    if (MODE == PRT_MODE_PACKET) {
+        while (T.sp > 0) {
+            --T.sp;
+            if (st.getT(T.sp) < T.hit.t) return st.get(T.sp); // the pop-time test of the reference
         }
-    }
-    (void)inf;
-    if (hit.t == maxT) hit.t = -1.0f;
-}
-
-// Scene::occluded (scene.cpp:69-94) over Bvh::occluded (bvh.cpp:576-654); PACKET selects the SoA box test
-// (vecmath.h:1504) and the per-lane semantics of the packet version, else the scalar bool test (:1449).  Fixed order:
-// first child popped first.  maxT is constant, so testing a child when its parent is visited equals testing it at its pop.
-// Counting builds keep failed children on the stack so that a box test is counted exactly when the reference performs it
-// (children still on the stack when the ray is found occluded are never tested there).
-template <bool PACKET, bool COUNT>
-__device__ __forceinline__ bool occluded(const DevScene& sc, const DevRay& r, float maxT, const Stack& st, Traffic& tr, uint32_t& overflow)
-{
-    DevHit dummy;
-    for (uint32_t m = 0; m < sc.bvhCount; m++) {
-        if (COUNT) tr.nBox++;
-        Box rb = root_box(sc, m);
-        if (!(PACKET ? box_soa(rb, r, maxT) : box_bool(rb, r, maxT))) continue;
-        uint32_t ref = sc.rootRef[m];
-        int sp = 0;
-        for (;;) {
-            bool descend = false;
-            if (ref == PRT_REF_DEAD) {
-                // counting build: a failed child, already counted at its pop
-            } else if (!(ref & PRT_REF_LEAF)) {
-                WideNode w;
-                load_wide(sc, ref, w);
-                bool h0 = PACKET ? box_soa(w.b0, r, maxT) : box_bool(w.b0, r, maxT);
-                bool h1 = PACKET ? box_soa(w.b1, r, maxT) : box_bool(w.b1, r, maxT);
-                if (sp + 2 >= PRT_STACK_MAX) { overflow = 1; break; }
-                if (COUNT) {
-                    st.put(sp++, h1 ? w.ref1 : PRT_REF_DEAD);
-                    tr.nBox++; // child 0 is popped next
-                } else if (h1) {
-                    st.put(sp++, w.ref1);
-                }
-                if (h0) {
-                    ref = w.ref0;
-                    descend = true;
-                }
-            } else {
-                if (leaf_intersect<true, PACKET, COUNT>(sc, ref, m, r, maxT, dummy, tr)) return true;
-            }
-            if (descend) continue;
-            if (sp == 0) break;
-            ref = st.get(--sp);
+        return PRT_REF_NONE;
+    } else if (MODE == PRT_MODE_SINGLE) {
+        if (T.sp == 0) return PRT_REF_NONE;
+        return st.get(--T.sp);
+    } else {
+        while (T.sp > 0) {
+            uint32_t r = st.get(--T.sp);
             if (COUNT) tr.nBox++;
+            if (r != PRT_REF_DEAD) return r;
+        }
+        return PRT_REF_NONE;
+    }
+}
+
+// Advance to the next BVH whose root box the ray passes; false when there is none left (the ray is finished).
+template <int MODE, bool COUNT>
+__device__ __forceinline__ bool tracer_next_bvh(const DevScene& sc, Tracer& T, Traffic& tr)
+{
+    for (;;) {
+        T.m++;
+        if (T.m >= sc.bvhCount) return false;
+        if (COUNT) tr.nBox++;
+        Box rb = root_box(sc, T.m);
+        bool pass;
+        if (MODE == PRT_MODE_PACKET) pass = box_soa(rb, T.r, T.hit.t);
+        else if (MODE == PRT_MODE_SINGLE) pass = box_bool(rb, T.r, T.hit.t);
+        else if (MODE == PRT_MODE_OCC_PACKET) pass = box_soa(rb, T.r, T.maxT);
+        else pass = box_bool(rb, T.r, T.maxT);
+        if (pass) {
+            T.ref = sc.rootRef[T.m];
+            T.sp = 0;
+            return true;
         }
     }
-    return false;
+}
+
+// One internal node: fetch its 64-byte record, test both children, choose where to go.
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr, uint32_t& overflow)
+{
+    WideNode w;
+    load_wide(sc, T.ref, w);
+    if (T.sp + 2 >= PRT_STACK_MAX) { // bvh.cpp:552, 627
+        overflow = 1;
+        T.ref = PRT_REF_NONE;
+        T.sp = 0;
+        T.m = sc.bvhCount;
+        return;
+    }
+    if (MODE == PRT_MODE_SINGLE) {
+        if (COUNT) tr.nBox += 2;
+        float t0 = box_t(w.b0, T.r), t1 = box_t(w.b1, T.r);
+        bool h0 = t0 < T.hit.t, h1 = t1 < T.hit.t;
+        if (h0 && h1) {
+            bool near0 = t0 < t1;
+            st.put(T.sp++, near0 ? w.ref1 : w.ref0);
+            T.ref = near0 ? w.ref0 : w.ref1;
+        } else if (h0) {
+            T.ref = w.ref0;
+        } else if (h1) {
+            T.ref = w.ref1;
+        } else {
+            T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+        }
+    } else if (MODE == PRT_MODE_PACKET) {
+        if (COUNT) tr.nBox += 2; // the reference pops and tests both children
+        float e0 = box_soa_entry(w.b0, T.r), e1 = box_soa_entry(w.b1, T.r);
+        bool rev = (T.rev >> (w.axis & 3u)) & 1u; // popped first = the second child when reverse
+        uint32_t firstRef = rev ? w.ref1 : w.ref0, laterRef = rev ? w.ref0 : w.ref1;
+        float firstE = rev ? e1 : e0, laterE = rev ? e0 : e1;
+        if (laterE < T.hit.t) st.putT(T.sp++, laterRef, laterE); // hit.t only shrinks: failing now means failing at the pop
+        if (firstE < T.hit.t) T.ref = firstRef;
+        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+    } else {
+        bool h0 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(w.b0, T.r, T.maxT) : box_bool(w.b0, T.r, T.maxT);
+        bool h1 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(w.b1, T.r, T.maxT) : box_bool(w.b1, T.r, T.maxT);
+        if (COUNT) {
+            st.put(T.sp++, h1 ? w.ref1 : PRT_REF_DEAD);
+            tr.nBox++; // child 0 is popped next
+        } else if (h1) {
+            st.put(T.sp++, w.ref1);
+        }
+        if (h0) T.ref = w.ref0;
+        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+    }
+}
+
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void tracer_leaf(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr)
+{
+    if (MODE == PRT_MODE_PACKET) {
+        leaf_intersect<false, true, COUNT>(sc, T.ref, T.m, T.r, T.hit.t, T.hit, tr);
+    } else if (MODE == PRT_MODE_SINGLE) {
+        leaf_intersect<false, false, COUNT>(sc, T.ref, T.m, T.r, T.hit.t, T.hit, tr);
+    } else {
+        if (leaf_intersect<true, MODE == PRT_MODE_OCC_PACKET, COUNT>(sc, T.ref, T.m, T.r, T.maxT, T.hit, tr)) {
+            T.occ = true;
+            T.ref = PRT_REF_NONE;
+            T.sp = 0;
+            T.m = sc.bvhCount; // finished
+            return;
+        }
+    }
+    T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+}
+
+__device__ __forceinline__ bool ref_is_internal(uint32_t ref) { return !(ref & PRT_REF_LEAF); }
+__device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & PRT_REF_LEAF) && ref != PRT_REF_NONE; }
+
+// The wave-level loop: every lane owns one ray at a time and takes a new one from `src` as soon as its own is
+// finished (persistent lanes, wave-aggregated claim: ballot + popcount + one atomic per wave).  "while-while": all
+// lanes that stand on an internal node step together until every lane stands on a leaf (or has nothing), then the
+// leaves are intersected together.
+//   Src: uint32_t count(); uint32_t* cursor(); void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev);
+//        void store_hit(uint32_t i, const DevHit&); void store_occ(uint32_t i, bool);
+template <int MODE, bool COUNT, class Src>
+__device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const Stack& st, Traffic& tr, uint32_t& overflow)
+{
+    const uint32_t n = src.count();
+    const uint32_t lane = threadIdx.x & 63u;
+    Tracer T;
+    T.ref = PRT_REF_NONE;
+    T.sp = 0;
+    T.m = 0;
+    bool active = false, exhausted = false;
+    uint32_t item = 0;
+    for (;;) {
+        unsigned long long need = __ballot(!active && !exhausted);
+        if (need) {
+            uint32_t leader = (uint32_t)__builtin_ctzll(need), base = 0;
+            if (lane == leader) base = atomicAdd(src.cursor(), (uint32_t)__popcll(need));
+            base = (uint32_t)__shfl((int)base, (int)leader, 64);
+            if (!active && !exhausted) {
+                item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (item < n) {
+                    Vec3 org, dir;
+                    float maxT;
+                    uint32_t rev;
+                    src.load(item, org, dir, maxT, rev);
+                    tracer_begin<MODE>(T, org, dir, maxT, rev);
+                    active = true;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (active && T.ref == PRT_REF_NONE) {
+            if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
+                if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
+                    if (T.hit.t == T.maxT) T.hit.t = -1.0f; // setMissForMaxT, scene.cpp:62
+                    src.store_hit(item, T.hit);
+                } else {
+                    src.store_occ(item, T.occ);
+                }
+                active = false;
+            }
+        }
+        while (__any(active && ref_is_internal(T.ref))) {
+            if (active && ref_is_internal(T.ref)) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+        }
+        if (active && ref_is_leaf(T.ref)) tracer_leaf<MODE, COUNT>(sc, T, st, tr);
+    }
 }
 
 // ---------------------------------------------------------------------------- surface + material

@@ -114,7 +114,7 @@ struct Surf5 { // what moves between slots at a compaction
 //
 // One iteration = shade + 4 traces; a packet needs 1 + maxDepth iterations, so an image needs
 // (samples/8)*(1+maxDepth)+1 iterations, enqueued back to back without host synchronisation.
-enum { Q_PRIMARY = 0, Q_SCATTER = 1, Q_OCC_PACKET = 2, Q_OCC_SINGLE = 3, Q_COUNT = 4 };
+enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
@@ -499,47 +499,48 @@ __global__ void init_groups_kernel(WfArgs A)
     A.gColor[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// One lane per queued ray.  MODE: Q_PRIMARY packet-nearest, Q_SCATTER single-nearest, Q_OCC_PACKET / Q_OCC_SINGLE any-hit.
+// Rays of one queue, results to the owner slots.
+struct QueueSrc {
+    const float4* qa;
+    const float4* qb;
+    uint32_t n;
+    uint32_t* cur;
+    float4* hitA;
+    uint2* hitB;
+    uint32_t* occl;
+    uint32_t owner; // of the lane's current ray
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ uint32_t* cursor() const { return cur; }
+    __device__ __forceinline__ void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev)
+    {
+        float4 ra = qa[i], rb = qb[i];
+        org = mk3(ra.x, ra.y, ra.z);
+        dir = mk3(ra.w, rb.x, rb.y);
+        maxT = rb.z;
+        uint32_t bits = asu(rb.w);
+        owner = bits & 0x3ffffffu;
+        rev = bits >> 26;
+    }
+    __device__ __forceinline__ void store_hit(uint32_t, const DevHit& h) const
+    {
+        hitA[owner] = make_float4(h.t, h.i, h.j, h.k);
+        hitB[owner] = make_uint2(h.primId, h.meshId);
+    }
+    __device__ __forceinline__ void store_occ(uint32_t, bool occ) const { occl[owner] = occ ? 1u : 0u; }
+};
+
+// Persistent lanes over one ray queue.  MODE = the queue id = the traversal mode.
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
 {
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
-    __shared__ float ldsT[(MODE == Q_PRIMARY ? PRT_STACK_LDS : 1) * PRT_BLOCK];
+    __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? PRT_STACK_LDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
-    const uint32_t n = A.qCount[MODE];
+    QueueSrc src{A.qA[MODE], A.qB[MODE], A.qCount[MODE], &A.qCount[Q_COUNT + MODE], A.hitA, A.hitB, A.occl, 0};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
-    for (uint32_t i = blockIdx.x * PRT_BLOCK + tid; i < n; i += gridDim.x * PRT_BLOCK) {
-        float4 ra = A.qA[MODE][i], rb = A.qB[MODE][i];
-        DevRay r;
-        r.org = mk3(ra.x, ra.y, ra.z);
-        r.dir = mk3(ra.w, rb.x, rb.y);
-        const float maxT = rb.z;
-        const uint32_t bits = asu(rb.w), owner = bits & 0x3ffffffu;
-        if (MODE == Q_PRIMARY || MODE == Q_SCATTER) {
-            DevHit h;
-            if (MODE == Q_PRIMARY) {
-                prepare_soa(r);
-                intersect_packet<COUNT>(A.sc, r, bits >> 26, maxT, h, st, tr, overflow);
-            } else {
-                prepare_single(r);
-                intersect_single<COUNT>(A.sc, r, maxT, h, st, tr, overflow);
-            }
-            A.hitA[owner] = make_float4(h.t, h.i, h.j, h.k);
-            A.hitB[owner] = make_uint2(h.primId, h.meshId);
-        } else {
-            bool occ;
-            if (MODE == Q_OCC_PACKET) {
-                prepare_soa(r);
-                occ = occluded<true, COUNT>(A.sc, r, maxT, st, tr, overflow);
-            } else {
-                prepare_single(r);
-                occ = occluded<false, COUNT>(A.sc, r, maxT, st, tr, overflow);
-            }
-            A.occl[owner] = occ ? 1u : 0u;
-        }
-    }
+    trace_loop<MODE, COUNT>(A.sc, src, st, tr, overflow);
     unsigned long long* C = A.counters;
     if (COUNT) {
         if (tr.nBox) atomicAdd(&C[2], (unsigned long long)tr.nBox);
@@ -552,54 +553,61 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
 // ============================================================================ row-level test kernels
 struct RaysArgs {
     DevScene sc;
-    int mode;
     uint32_t n;
     const float* org;
     const float* dir;
     float maxT;
     prt_hit* hits;
+    uint32_t* cursor;
     uint32_t* spill;
     uint32_t spillStride;
     unsigned long long* counters;
 };
 
+struct ArraySrc {
+    const RaysArgs* A;
+    int mode;
+    __device__ __forceinline__ uint32_t count() const { return A->n; }
+    __device__ __forceinline__ uint32_t* cursor() const { return A->cursor; }
+    __device__ __forceinline__ void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev) const
+    {
+        org = mk3(A->org[3 * i], A->org[3 * i + 1], A->org[3 * i + 2]);
+        dir = mk3(A->dir[3 * i], A->dir[3 * i + 1], A->dir[3 * i + 2]);
+        maxT = A->maxT;
+        rev = 0;
+        if (mode == PRT_MODE_PACKET) { // avgDir = lane-ordered sum of the packet's 8 directions / 8 (camera.cpp:56,70)
+            uint32_t g = i & ~7u;
+            Vec3 avg = mk3(0, 0, 0);
+            for (uint32_t l = 0; l < 8; l++) avg = add3(avg, mk3(A->dir[3 * (g + l)], A->dir[3 * (g + l) + 1], A->dir[3 * (g + l) + 2]));
+            avg = div3s(avg, 8.0f);
+            rev = (avg.x < 0.0f ? 1u : 0u) | (avg.y < 0.0f ? 2u : 0u) | (avg.z < 0.0f ? 4u : 0u);
+        }
+    }
+    __device__ __forceinline__ void store_hit(uint32_t i, const DevHit& h) const
+    {
+        prt_hit o;
+        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = h.primId; o.meshId = h.meshId;
+        A->hits[i] = o;
+    }
+    __device__ __forceinline__ void store_occ(uint32_t i, bool occ) const
+    {
+        prt_hit o;
+        o.t = occ ? 1.0f : 0.0f; o.i = o.j = o.k = 0.0f; o.primId = 0; o.meshId = 0;
+        A->hits[i] = o;
+    }
+};
+
+template <int MODE>
 __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
 {
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
     __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, gbase = lane & ~7u;
+    const uint32_t tid = threadIdx.x;
     const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
-    uint32_t i = blockIdx.x * PRT_BLOCK + tid;
-    bool valid = i < A.n;
-    uint32_t ii = valid ? i : 0;
-    DevRay r;
-    r.org = mk3(A.org[3 * ii], A.org[3 * ii + 1], A.org[3 * ii + 2]);
-    r.dir = mk3(A.dir[3 * ii], A.dir[3 * ii + 1], A.dir[3 * ii + 2]);
+    ArraySrc src{&A, MODE};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
-    DevHit h{0, 0, 0, 0, 0, 0};
-    if (A.mode == 0) {
-        prepare_single(r);
-        if (valid) intersect_single<false>(A.sc, r, A.maxT, h, st, tr, overflow);
-    } else if (A.mode == 1) {
-        prepare_soa(r);
-        Vec3 avg = mk3(0, 0, 0);
-        for (uint32_t l = 0; l < 8; l++) avg = add3(avg, sh3(r.dir, gbase + l));
-        avg = div3s(avg, 8.0f);
-        uint32_t rev = (avg.x < 0.0f ? 1u : 0u) | (avg.y < 0.0f ? 2u : 0u) | (avg.z < 0.0f ? 4u : 0u);
-        if (valid) intersect_packet<false>(A.sc, r, rev, A.maxT, h, st, tr, overflow);
-    } else if (A.mode == 2) {
-        prepare_single(r);
-        if (valid) h.t = occluded<false, false>(A.sc, r, A.maxT, st, tr, overflow) ? 1.0f : 0.0f;
-    } else {
-        prepare_soa(r);
-        if (valid) h.t = occluded<true, false>(A.sc, r, A.maxT, st, tr, overflow) ? 1.0f : 0.0f;
-    }
-    if (valid) {
-        prt_hit o;
-        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = h.primId; o.meshId = h.meshId;
-        A.hits[i] = o;
-    }
+    trace_loop<MODE, false>(A.sc, src, st, tr, overflow);
     if (overflow) atomicAdd(&A.counters[7], 1ull);
 }
 
@@ -753,7 +761,7 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
 template <bool COUNT>
 static void wf_iteration(const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
 {
-    (void)hipMemsetAsync(A.qCount, 0, Q_COUNT * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(A.qCount, 0, 2 * Q_COUNT * sizeof(uint32_t), s); // queue counts + claim cursors
     hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(shadeBlocks), dim3(PRT_BLOCK), 0, s, A);
     hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
     hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
@@ -1207,8 +1215,13 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     HIP_TRY(hipMemcpy(dorg, org, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ddir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
-    RaysArgs A{c->sc, mode, n, dorg, ddir, maxT, dh, c->spill, c->spillThreads, c->counters};
-    hipLaunchKernelGGL(rays_kernel, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
+    HIP_TRY(hipMemsetAsync(c->work, 0, 2 * Q_COUNT * sizeof(uint32_t), c->stream));
+    RaysArgs A{c->sc, n, dorg, ddir, maxT, dh, c->work, c->spill, c->spillThreads, c->counters};
+    blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
+    if (mode == 0) hipLaunchKernelGGL(rays_kernel<PRT_MODE_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
+    else if (mode == 1) hipLaunchKernelGGL(rays_kernel<PRT_MODE_PACKET>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
+    else if (mode == 2) hipLaunchKernelGGL(rays_kernel<PRT_MODE_OCC_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
+    else hipLaunchKernelGGL(rays_kernel<PRT_MODE_OCC_PACKET>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("rays_kernel launch: ") + hipGetErrorString(le));
     HIP_TRY(hipStreamSynchronize(c->stream));
