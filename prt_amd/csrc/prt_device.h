@@ -86,6 +86,7 @@ __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 struct DevRay {
     Vec3 org, dir, inv;
     bool swapXZ, swapYZ;
+    bool fast; // all three reciprocal direction components finite: no slab product can be NaN
     // per-ray constants of the watertight test (triangle.cpp:118-119): 1/d.z and (d.x, d.y)/d.z AFTER the axis swap
     float invDz, shearX, shearY;
 };
@@ -98,6 +99,9 @@ __device__ __forceinline__ void prepare_shear(DevRay& r)
     r.invDz = 1.0f / d.z;
     r.shearX = d.x * r.invDz;
     r.shearY = d.y * r.invDz;
+    const float big = 3.402823466e+38f;
+    r.fast = (fabsf(r.inv.x) <= big) && (fabsf(r.inv.y) <= big) && (fabsf(r.inv.z) <= big) && (fabsf(r.org.x) <= big) &&
+             (fabsf(r.org.y) <= big) && (fabsf(r.org.z) <= big);
 }
 
 struct DevHit {
@@ -106,7 +110,8 @@ struct DevHit {
 };
 
 struct Traffic {
-    uint32_t nBox, nTri, nHit, nTap;
+    unsigned long long nBox, nTri; // a persistent trace lane can exceed 2^32
+    uint32_t nHit, nTap;
 };
 
 // ray.h:26-40: swap axis from the SIGNED components (Vector3f::GetLongestElement, vecmath.h:216)
@@ -138,56 +143,71 @@ struct Box {
     Vec3 lo, hi;
 };
 
+// SSE min/max return their SECOND operand when either is NaN; a slab product is NaN only when a box plane passes
+// through the ray origin AND that direction component is exactly zero (0 * inf).  A ray whose three reciprocal
+// components are finite (DevRay::fast, the overwhelmingly common case) can never produce one, and for NaN-free inputs
+// v_min_f32/v_max_f32 give the same values as the SSE selects up to the sign of a zero, which only ever feeds
+// comparisons.  FAST = false keeps the exact select form for the remaining rays.
+template <bool FAST>
+__device__ __forceinline__ float bmin(float a, float b) { return FAST ? __builtin_fminf(a, b) : (a < b ? a : b); }
+template <bool FAST>
+__device__ __forceinline__ float bmax(float a, float b) { return FAST ? __builtin_fmaxf(a, b) : (a > b ? a : b); }
+
+template <bool FAST>
 __device__ __forceinline__ void slabs(const Box& b, const DevRay& r, float t0[3], float t1[3])
 {
     float a, c;
-    a = (b.lo.x - r.org.x) * r.inv.x; c = (b.hi.x - r.org.x) * r.inv.x; t0[0] = sse_min(a, c); t1[0] = sse_max(a, c);
-    a = (b.lo.y - r.org.y) * r.inv.y; c = (b.hi.y - r.org.y) * r.inv.y; t0[1] = sse_min(a, c); t1[1] = sse_max(a, c);
-    a = (b.lo.z - r.org.z) * r.inv.z; c = (b.hi.z - r.org.z) * r.inv.z; t0[2] = sse_min(a, c); t1[2] = sse_max(a, c);
+    a = (b.lo.x - r.org.x) * r.inv.x; c = (b.hi.x - r.org.x) * r.inv.x; t0[0] = bmin<FAST>(a, c); t1[0] = bmax<FAST>(a, c);
+    a = (b.lo.y - r.org.y) * r.inv.y; c = (b.hi.y - r.org.y) * r.inv.y; t0[1] = bmin<FAST>(a, c); t1[1] = bmax<FAST>(a, c);
+    a = (b.lo.z - r.org.z) * r.inv.z; c = (b.hi.z - r.org.z) * r.inv.z; t0[2] = bmin<FAST>(a, c); t1[2] = bmax<FAST>(a, c);
 }
 
 // vecmath.h:1402-1424.  4th SSE lane: t0 = -inf, t1 = +inf; reductions op(op(a0,a2),op(a1,a3)) (:1325-1345)
-__device__ __forceinline__ float box_t(const Box& b, const DevRay& r)
+template <bool FAST>
+__device__ __forceinline__ float box_t_impl(const Box& b, const DevRay& r)
 {
     float t0[3], t1[3];
-    slabs(b, r, t0, t1);
+    slabs<FAST>(b, r, t0, t1);
     const float inf = __builtin_inff();
-    float max_t0 = sse_max(sse_max(t0[0], t0[2]), sse_max(t0[1], -inf));
-    float min_t1 = sse_min(sse_min(t1[0], t1[2]), sse_min(t1[1], inf));
+    float max_t0 = bmax<FAST>(bmax<FAST>(t0[0], t0[2]), bmax<FAST>(t0[1], -inf));
+    float min_t1 = bmin<FAST>(bmin<FAST>(t1[0], t1[2]), bmin<FAST>(t1[1], inf));
     return (min_t1 < max_t0) ? inf : max_t0;
 }
+__device__ __forceinline__ float box_t(const Box& b, const DevRay& r) { return r.fast ? box_t_impl<true>(b, r) : box_t_impl<false>(b, r); }
 
 // vecmath.h:1449-1466.  4th lane: t0 = min(-FLT_MAX, maxT), t1 = max(-FLT_MAX, maxT)
-__device__ __forceinline__ bool box_bool(const Box& b, const DevRay& r, float maxT)
+template <bool FAST>
+__device__ __forceinline__ bool box_bool_impl(const Box& b, const DevRay& r, float maxT)
 {
     float t0[3], t1[3];
-    slabs(b, r, t0, t1);
+    slabs<FAST>(b, r, t0, t1);
     const float lowest = -3.402823466e+38f;
     float w0 = sse_min(lowest, maxT), w1 = sse_max(lowest, maxT);
-    float max_t0 = sse_max(sse_max(t0[0], t0[2]), sse_max(t0[1], w0));
-    float min_t1 = sse_min(sse_min(t1[0], t1[2]), sse_min(t1[1], w1));
+    float max_t0 = bmax<FAST>(bmax<FAST>(t0[0], t0[2]), bmax<FAST>(t0[1], w0));
+    float min_t1 = bmin<FAST>(bmin<FAST>(t1[0], t1[2]), bmin<FAST>(t1[1], w1));
     return min_t1 > max_t0;
 }
-
-// vecmath.h:1504-1518, one lane
-__device__ __forceinline__ bool box_soa(const Box& b, const DevRay& r, float maxT)
+__device__ __forceinline__ bool box_bool(const Box& b, const DevRay& r, float maxT)
 {
-    float t0[3], t1[3];
-    slabs(b, r, t0, t1);
-    float max_t0 = sse_max(t0[0], sse_max(t0[1], t0[2]));
-    float min_t1 = sse_min(t1[0], sse_min(t1[1], t1[2]));
-    return (max_t0 < maxT) && (min_t1 >= max_t0);
+    return r.fast ? box_bool_impl<true>(b, r, maxT) : box_bool_impl<false>(b, r, maxT);
 }
 
-// the hit.t-independent part of box_soa: max_t0 when min_t1 >= max_t0, else +inf (so that `entry < hit.t` is the whole test)
-__device__ __forceinline__ float box_soa_entry(const Box& b, const DevRay& r)
+// vecmath.h:1504-1518, one lane: returns max_t0 when min_t1 >= max_t0, else +inf, so that `entry < limit` is the whole
+// test (max_t0 < maxT && min_t1 >= max_t0)
+template <bool FAST>
+__device__ __forceinline__ float box_soa_entry_impl(const Box& b, const DevRay& r)
 {
     float t0[3], t1[3];
-    slabs(b, r, t0, t1);
-    float max_t0 = sse_max(t0[0], sse_max(t0[1], t0[2]));
-    float min_t1 = sse_min(t1[0], sse_min(t1[1], t1[2]));
+    slabs<FAST>(b, r, t0, t1);
+    float max_t0 = bmax<FAST>(t0[0], bmax<FAST>(t0[1], t0[2]));
+    float min_t1 = bmin<FAST>(t1[0], bmin<FAST>(t1[1], t1[2]));
     return (min_t1 >= max_t0) ? max_t0 : __builtin_inff();
 }
+__device__ __forceinline__ float box_soa_entry(const Box& b, const DevRay& r)
+{
+    return r.fast ? box_soa_entry_impl<true>(b, r) : box_soa_entry_impl<false>(b, r);
+}
+__device__ __forceinline__ bool box_soa(const Box& b, const DevRay& r, float maxT) { return box_soa_entry(b, r) < maxT; }
 
 // ---------------------------------------------------------------------------- triangle
 // triangle.cpp:90-166, one lane.  Returns t, or -1 (kNoIntersection).

@@ -38,6 +38,14 @@ __device__ __forceinline__ uint32_t nth_set(uint32_t m, uint32_t n)
     return m ? (uint32_t)__builtin_ctz(m) : 0u;
 }
 
+// sum over the wave's active lanes (all 64 lanes must call it); result valid in every lane
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
 __device__ __forceinline__ float shf(float v, uint32_t srcLane) { return __shfl(v, (int)srcLane, 64); }
 __device__ __forceinline__ uint32_t shu(uint32_t v, uint32_t srcLane) { return (uint32_t)__shfl((int)v, (int)srcLane, 64); }
 __device__ __forceinline__ Vec3 sh3(Vec3 v, uint32_t srcLane) { return mk3(shf(v.x, srcLane), shf(v.y, srcLane), shf(v.z, srcLane)); }
@@ -461,15 +469,19 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
             A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
         }
     }
-    // ---- statistics
-    unsigned long long* C = A.counters;
-    if (nRays) atomicAdd(&C[0], nRays);
-    if (nOccl) atomicAdd(&C[1], nOccl);
-    if (COUNT) {
-        if (tr.nHit) atomicAdd(&C[4], (unsigned long long)tr.nHit);
-        if (tr.nTap) atomicAdd(&C[5], (unsigned long long)tr.nTap);
+    // ---- statistics: one atomic per wave and counter (per-lane atomics on one address would serialise the launch)
+    {
+        unsigned long long* C = A.counters;
+        uint32_t r = wave_sum((uint32_t)nRays), o = wave_sum((uint32_t)nOccl), px = wave_sum((uint32_t)nPx);
+        uint32_t nh = COUNT ? wave_sum(tr.nHit) : 0u, nt = COUNT ? wave_sum(tr.nTap) : 0u;
+        if (lane == 0) {
+            if (r) atomicAdd(&C[0], (unsigned long long)r);
+            if (o) atomicAdd(&C[1], (unsigned long long)o);
+            if (nh) atomicAdd(&C[4], (unsigned long long)nh);
+            if (nt) atomicAdd(&C[5], (unsigned long long)nt);
+            if (px) atomicAdd(&C[6], (unsigned long long)px);
+        }
     }
-    if (nPx) atomicAdd(&C[6], nPx);
 }
 
 // Assigns pixels to the groups of a pass (tile-major order, row-major inside a 16x16 tile, main.cpp:132-138) and
@@ -543,9 +555,19 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     trace_loop<MODE, COUNT>(A.sc, src, st, tr, overflow);
     unsigned long long* C = A.counters;
     if (COUNT) {
-        if (tr.nBox) atomicAdd(&C[2], (unsigned long long)tr.nBox);
-        if (tr.nTri) atomicAdd(&C[3], (unsigned long long)tr.nTri);
-        if (tr.nTap) atomicAdd(&C[5], (unsigned long long)tr.nTap);
+        // 64-bit per-wave sums (a persistent lane can count more than 2^32 box tests)
+        unsigned long long b = tr.nBox, t = tr.nTri, p = tr.nTap;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            b += (unsigned long long)__shfl_xor((long long)b, o, 64);
+            t += (unsigned long long)__shfl_xor((long long)t, o, 64);
+            p += (unsigned long long)__shfl_xor((long long)p, o, 64);
+        }
+        if ((tid & 63u) == 0) {
+            if (b) atomicAdd(&C[2], b);
+            if (t) atomicAdd(&C[3], t);
+            if (p) atomicAdd(&C[5], p);
+        }
     }
     if (overflow) atomicAdd(&C[7], 1ull);
 }
