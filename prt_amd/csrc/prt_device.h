@@ -612,14 +612,24 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
     T.m = 0;
     bool active = false, exhausted = false;
     uint32_t item = 0;
+    // The wave reserves ranges of the queue CHUNK rays at a time (one returning atomic per range, not per refill) and
+    // hands them to its lanes as they become free; both bounds are wave-uniform.
+    const uint32_t totalWaves = gridDim.x * (PRT_BLOCK / 64);
+    uint32_t chunk = n / (totalWaves * 4u);
+    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    uint32_t rangeNext = 0, rangeEnd = 0;
     for (;;) {
         unsigned long long need = __ballot(!active && !exhausted);
         if (need) {
-            uint32_t leader = (uint32_t)__builtin_ctzll(need), base = 0;
-            if (lane == leader) base = atomicAdd(src.cursor(), (uint32_t)__popcll(need));
-            base = (uint32_t)__shfl((int)base, (int)leader, 64);
+            const uint32_t k = (uint32_t)__popcll(need), avail = rangeEnd - rangeNext;
+            uint32_t newBase = 0;
+            if (avail < k) { // wave-uniform
+                if (lane == 0) newBase = atomicAdd(src.cursor(), chunk);
+                newBase = (uint32_t)__shfl((int)newBase, 0, 64);
+            }
             if (!active && !exhausted) {
-                item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                item = (r < avail) ? rangeNext + r : newBase + (r - avail);
                 if (item < n) {
                     Vec3 org, dir;
                     float maxT;
@@ -630,6 +640,12 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                 } else {
                     exhausted = true;
                 }
+            }
+            if (avail < k) {
+                rangeNext = newBase + (k - avail);
+                rangeEnd = newBase + chunk;
+            } else {
+                rangeNext += k;
             }
         }
         if (!__any(active)) break;

@@ -124,6 +124,7 @@ struct Surf5 { // what moves between slots at a compaction
 // (samples/8)*(1+maxDepth)+1 iterations, enqueued back to back without host synchronisation.
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
+#define PRT_QSHARDS 16
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
 
@@ -152,27 +153,15 @@ struct WfArgs {
     // ray queues
     float4* qA[Q_COUNT]; // org.xyz dir.x
     float4* qB[Q_COUNT]; // dir.yz maxT bits(owner | reverseBits << 26)
-    uint32_t* qCount;    // Q_COUNT counters
+    // Queue q is split into PRT_QSHARDS regions of shardCap entries; blocks append to region blockIdx % PRT_QSHARDS, so that
+    // the returning atomics that reserve space are spread over 16 addresses per queue (one address takes ~88 of them
+    // per microsecond, MI355X_MICROARCH.md "dequeue").  qWork: [0..3] claim cursors of the trace kernels,
+    // [4 + q*PRT_QSHARDS + shard] entries in that region.
+    uint32_t* qWork;
+    uint32_t shardCap;
     uint32_t* spill;
     uint32_t spillStride;
 };
-
-// Append this lane's ray to queue q: ranks by wave ballot + popcount, one atomic per wave.
-__device__ __forceinline__ void emit_ray(const WfArgs& A, int q, bool want, Vec3 org, Vec3 dir, float maxT, uint32_t bits)
-{
-    unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    uint32_t lane = lane_id();
-    uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&A.qCount[q], (uint32_t)__popcll(mask));
-    base = shu(base, leader);
-    if (want) {
-        uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        A.qA[q][idx] = make_float4(org.x, org.y, org.z, dir.x);
-        A.qB[q][idx] = make_float4(dir.y, dir.z, maxT, asf(bits));
-    }
-}
 
 template <bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
@@ -445,12 +434,39 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         phase = PH_WAIT_PRIMARY;
     }
 
-    // ---- converged part: pack the rays of the next iteration into the queues
-    const uint32_t owner = gs;
-    emit_ray(A, Q_PRIMARY, emitPrimary, eOrg, eDir, 100000.0f, owner | (reverseBits << 26));
-    emit_ray(A, Q_SCATTER, emitScatter, eOrg, eDir, kFar, owner);
-    emit_ray(A, Q_OCC_PACKET, emitShadow && shadowPacket, sOrg, sDir, kFar - kEpsilon, owner);
-    emit_ray(A, Q_OCC_SINGLE, emitShadow && !shadowPacket, sOrg, sDir, kFar - kEpsilon, owner);
+    // ---- converged part: pack the rays of the next iteration into the queues.  Lane rank by wave ballot + popcount,
+    // wave offset by an LDS atomic, one global (returning) atomic per block and queue on the block's shard.
+    {
+        __shared__ uint32_t blkCount[Q_COUNT], blkBase[Q_COUNT];
+        if (tid < Q_COUNT) blkCount[tid] = 0;
+        __syncthreads();
+        const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
+        uint32_t waveOff[Q_COUNT], rank[Q_COUNT];
+#pragma unroll
+        for (int q = 0; q < Q_COUNT; q++) {
+            unsigned long long mask = __ballot(want[q]);
+            rank[q] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t off = 0;
+            if (mask != 0ull && lane == 0) off = atomicAdd(&blkCount[q], (uint32_t)__popcll(mask));
+            waveOff[q] = shu(off, 0);
+        }
+        __syncthreads();
+        const uint32_t shard = blockIdx.x % PRT_QSHARDS;
+        if (tid < Q_COUNT && blkCount[tid] != 0u) blkBase[tid] = atomicAdd(&A.qWork[4 + tid * PRT_QSHARDS + shard], blkCount[tid]);
+        __syncthreads();
+        const uint32_t owner = gs;
+#pragma unroll
+        for (int q = 0; q < Q_COUNT; q++) {
+            if (!want[q]) continue;
+            uint32_t idx = shard * A.shardCap + blkBase[q] + waveOff[q] + rank[q];
+            const bool shadow = q >= Q_OCC_PACKET;
+            Vec3 o = shadow ? sOrg : eOrg, d = shadow ? sDir : eDir;
+            float maxT = (q == Q_PRIMARY) ? 100000.0f : (q == Q_SCATTER ? kFar : kFar - kEpsilon);
+            uint32_t bits = (q == Q_PRIMARY) ? (owner | (reverseBits << 26)) : owner;
+            A.qA[q][idx] = make_float4(o.x, o.y, o.z, d.x);
+            A.qB[q][idx] = make_float4(d.y, d.z, maxT, asf(bits));
+        }
+    }
 
     // ---- store state
     if (inRange && (info >> 20) != PH_DONE) {
@@ -511,10 +527,12 @@ __global__ void init_groups_kernel(WfArgs A)
     A.gColor[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// Rays of one queue, results to the owner slots.
+// Rays of one (sharded) queue, results to the owner slots.
 struct QueueSrc {
     const float4* qa;
     const float4* qb;
+    uint32_t shardCount[PRT_QSHARDS];
+    uint32_t shardCap;
     uint32_t n;
     uint32_t* cur;
     float4* hitA;
@@ -525,7 +543,16 @@ struct QueueSrc {
     __device__ __forceinline__ uint32_t* cursor() const { return cur; }
     __device__ __forceinline__ void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev)
     {
-        float4 ra = qa[i], rb = qb[i];
+        // virtual index -> (shard, offset)
+        uint32_t v = i, base = 0;
+#pragma unroll
+        for (int k = 0; k < PRT_QSHARDS - 1; k++) {
+            bool next = v >= shardCount[k];
+            v -= next ? shardCount[k] : 0u;
+            base += next ? shardCap : 0u;
+            if (!next) break;
+        }
+        float4 ra = qa[base + v], rb = qb[base + v];
         org = mk3(ra.x, ra.y, ra.z);
         dir = mk3(ra.w, rb.x, rb.y);
         maxT = rb.z;
@@ -549,7 +576,21 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? PRT_STACK_LDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
-    QueueSrc src{A.qA[MODE], A.qB[MODE], A.qCount[MODE], &A.qCount[Q_COUNT + MODE], A.hitA, A.hitB, A.occl, 0};
+    QueueSrc src;
+    src.qa = A.qA[MODE];
+    src.qb = A.qB[MODE];
+    src.n = 0;
+#pragma unroll
+    for (int k = 0; k < PRT_QSHARDS; k++) {
+        src.shardCount[k] = A.qWork[4 + MODE * PRT_QSHARDS + k];
+        src.n += src.shardCount[k];
+    }
+    src.shardCap = A.shardCap;
+    src.cur = &A.qWork[MODE];
+    src.hitA = A.hitA;
+    src.hitB = A.hitB;
+    src.occl = A.occl;
+    src.owner = 0;
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
     trace_loop<MODE, COUNT>(A.sc, src, st, tr, overflow);
@@ -783,7 +824,7 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
 template <bool COUNT>
 static void wf_iteration(const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
 {
-    (void)hipMemsetAsync(A.qCount, 0, 2 * Q_COUNT * sizeof(uint32_t), s); // queue counts + claim cursors
+    (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), s); // claim cursors + shard counts
     hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(shadeBlocks), dim3(PRT_BLOCK), 0, s, A);
     hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
     hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
@@ -817,8 +858,8 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
-    HIP_TRY(hipMalloc(&c->work, 256));
-    HIP_TRY(hipMemset(c->work, 0, 256));
+    HIP_TRY(hipMalloc(&c->work, 1024));
+    HIP_TRY(hipMemset(c->work, 0, 1024));
     HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
     *out = c;
@@ -1061,7 +1102,7 @@ static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
     size_t need = 0;
     need += 3 * al(groups * sizeof(uint32_t)) + al(groups * sizeof(float4));
     need += 7 * al(slots * sizeof(float4)) + al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t));
-    need += 2 * Q_COUNT * al(slots * sizeof(float4));
+    need += 2 * Q_COUNT * al((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
     if (need > c->wfBytes) {
         if (c->wfBuffer) (void)hipFree(c->wfBuffer);
         c->wfBuffer = nullptr;
@@ -1081,8 +1122,8 @@ static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
     A.hitB = (uint2*)take(slots * sizeof(uint2));
     A.occl = (uint32_t*)take(slots * sizeof(uint32_t));
     for (int q = 0; q < Q_COUNT; q++) {
-        A.qA[q] = (float4*)take(slots * sizeof(float4));
-        A.qB[q] = (float4*)take(slots * sizeof(float4));
+        A.qA[q] = (float4*)take((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
+        A.qB[q] = (float4*)take((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
     }
     return PRT_HIP_OK;
 }
@@ -1133,7 +1174,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     }
     if (totalWork > 0xffffffffull) return fail(PRT_HIP_EINVAL, "rectangle too large");
     A.rgb = d_rgb;
-    A.qCount = c->work;
+    A.qWork = c->work;
     A.counters = c->counters;
     const uint32_t traceBlocks = (uint32_t)persistent_blocks(c);
     int rc = ensure_launch_resources(c, traceBlocks);
@@ -1160,6 +1201,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         A.groupCount = (uint32_t)std::min<uint64_t>(passGroups, totalWork - base);
         hipLaunchKernelGGL(init_groups_kernel, dim3((A.groupCount + 255) / 256), dim3(256), 0, s, A);
         const uint32_t shadeBlocks = (uint32_t)(((uint64_t)A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
+        A.shardCap = ((shadeBlocks + PRT_QSHARDS - 1) / PRT_QSHARDS) * PRT_BLOCK;
         for (uint32_t it = 0; it < iterations; it++) {
             if (p->countTraffic) wf_iteration<true>(A, shadeBlocks, traceBlocks, s);
             else wf_iteration<false>(A, shadeBlocks, traceBlocks, s);
@@ -1237,7 +1279,7 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     HIP_TRY(hipMemcpy(dorg, org, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ddir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->work, 0, 2 * Q_COUNT * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->work, 0, 1024, c->stream));
     RaysArgs A{c->sc, n, dorg, ddir, maxT, dh, c->work, c->spill, c->spillThreads, c->counters};
     blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
     if (mode == 0) hipLaunchKernelGGL(rays_kernel<PRT_MODE_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
