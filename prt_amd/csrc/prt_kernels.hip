@@ -163,9 +163,26 @@ struct WfArgs {
     uint32_t spillStride;
 };
 
+// Diagnostic build (-DPRT_STAMP): per-segment wave time of the shade kernel, summed into counters[8..15].
+#ifdef PRT_STAMP
+#define STAMP(k)                                                                                    \
+    do {                                                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        stampAcc[k] += t_ - stampLast;                                                              \
+        stampLast = t_;                                                                             \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 template <bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
 {
+#ifdef PRT_STAMP
+    unsigned long long stampAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, slot = lane & 7u, gbase = lane & ~7u;
     const uint32_t g = (blockIdx.x * PRT_BLOCK + tid) >> 3;
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         color = mk3(c.x, c.y, c.z);
     }
     const uint32_t x = pixel & 0xffffu, y = pixel >> 16;
+    STAMP(0);
 
     // slot state
     Vec3 pos = mk3(0, 0, 0), rayDir = mk3(0, 0, 0), normal = mk3(0, 0, 0), beta = mk3(1, 1, 1), result = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         }
     }
 
+    STAMP(1);
     if (needBounce) {
         // ---- one bounce (path_tracer.cpp:131-190 and the Russian roulette of :258-265)
         const bool active = slot < alive;
@@ -400,6 +419,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         phase = PH_WAIT_BOUNCE;
     }
 
+    STAMP(2);
     if (needEnd) {
         // ---- Σ result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71)
         Vec3 res = mk3(0.0f, 0.0f, 0.0f);
@@ -434,6 +454,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         phase = PH_WAIT_PRIMARY;
     }
 
+    STAMP(3);
     // ---- converged part: pack the rays of the next iteration into the queues.  Lane rank by wave ballot + popcount,
     // wave offset by an LDS atomic, one global (returning) atomic per block and queue on the block's shard.
     {
@@ -468,6 +489,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         }
     }
 
+    STAMP(4);
     // ---- store state
     if (inRange && (info >> 20) != PH_DONE) {
         if (phase == PH_WAIT_BOUNCE) {
@@ -485,6 +507,12 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
             A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
         }
     }
+    STAMP(5);
+#ifdef PRT_STAMP
+    if (lane == 0)
+        for (int k = 0; k < 6; k++) atomicAdd(&A.counters[8 + k], stampAcc[k]);
+    if (lane == 0) atomicAdd(&A.counters[15], 1ull);
+#endif
     // ---- statistics: one atomic per wave and counter (per-lane atomics on one address would serialise the launch)
     {
         unsigned long long* C = A.counters;
@@ -860,8 +888,8 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipMalloc(&c->work, 1024));
     HIP_TRY(hipMemset(c->work, 0, 1024));
-    HIP_TRY(hipMalloc(&c->counters, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->counters, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
     *out = c;
     return PRT_HIP_OK;
 }
@@ -1185,7 +1213,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     const uint32_t passGroups = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(totalWork, 1), kMaxGroupsPerPass);
     if ((rc = wf_layout(c, passGroups, A))) return rc;
 
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), s));
     if (c->eventsUsed == c->events.size()) {
         hipEvent_t a = nullptr, b = nullptr;
         HIP_TRY(hipEventCreate(&a));
@@ -1236,8 +1264,13 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     if (!c || !st) return fail(PRT_HIP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long h[8];
+    unsigned long long h[16];
     HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef PRT_STAMP
+    fprintf(stderr, "shade stamps (avg cycles per wave): load %.0f consume %.0f bounce %.0f end+camera %.0f emit %.0f store %.0f  waves %llu\n",
+            (double)h[8] / h[15], (double)h[9] / h[15], (double)h[10] / h[15], (double)h[11] / h[15], (double)h[12] / h[15],
+            (double)h[13] / h[15], h[15]);
+#endif
     st->raysTraced = h[0];
     st->occludedTraced = h[1];
     st->nBox = h[2];
