@@ -127,6 +127,20 @@ enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
+#define SLOT_LIGHT_SET 4u
+
+// streaming (touch-once-per-iteration) state goes around the caches' retention so that the BVH stays resident
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    f4_t v = __builtin_nontemporal_load((const f4_t*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float4 v)
+{
+    f4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (f4_t*)p);
+}
 
 struct WfArgs {
     DevScene sc;
@@ -142,17 +156,21 @@ struct WfArgs {
     unsigned long long* counters; // rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
     // per group
     uint32_t* gRng;
-    uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20
+    uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20 | alive at depth 0 << 24
     uint32_t* gPixel; // x | y << 16, 0xffffffff = no pixel (outside the rectangle / not this rank's tile)
     float4* gColor;
-    // per slot (8 per group)
-    float4 *S0, *S1, *S2, *S3, *S4, *S5, *S6;
+    // per slot (8 per group): what a path carries from one iteration to the next (68 B)
+    float4* S0; // pos.xyz, bits(material of the surface the path stands on)
+    float4* S1; // shading normal xyz, bits(slot flags)
+    float4* S2; // direction of the ray in flight (primary or scatter) xyz
+    float4* S3; // beta.xyz
+    float4* S4; // result.xyz -- belongs to the SLOT, not the path: it stays behind when the path dies or is compacted away
     float4* hitA;   // t i j k
     uint2* hitB;    // primId meshId
     uint32_t* occl; // 1 = occluded
     // ray queues
-    float4* qA[Q_COUNT]; // org.xyz dir.x
-    float4* qB[Q_COUNT]; // dir.yz maxT bits(owner | reverseBits << 26)
+    uint32_t* qE[Q_COUNT]; // queued ray = owner slot (26 bits) | reverseBits << 26 | lightSet << 29; the trace kernels rebuild
+                           // the ray from the owner's state
     // Queue q is split into PRT_QSHARDS regions of shardCap entries; blocks append to region blockIdx % PRT_QSHARDS, so that
     // the returning atomics that reserve space are spread over 16 addresses per queue (one address takes ~88 of them
     // per microsecond, MI355X_MICROARCH.md "dequeue").  qWork: [0..3] claim cursors of the trace kernels,
@@ -200,7 +218,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
     unsigned long long nRays = 0, nOccl = 0, nPx = 0;
 
     uint32_t info = inRange ? A.gInfo[g] : ((uint32_t)PH_DONE << 20);
-    uint32_t phase = info >> 20, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
+    uint32_t phase = (info >> 20) & 0xfu, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
+    uint32_t alive0 = (info >> 24) & 0xfu; // slots that have held a path in this packet: the others' result is still 0
+    const uint32_t aliveAtEntry = (phase == PH_WAIT_BOUNCE) ? alive : 0u;
     uint32_t rng = 0, pixel = 0xffffffffu;
     Vec3 color = mk3(0, 0, 0);
     if (phase != PH_DONE) {
@@ -219,7 +239,6 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
 
     bool needBounce = false, needEnd = false, needCamera = false;
     bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
-    Vec3 eOrg = mk3(0, 0, 0), eDir = mk3(0, 0, 0), sOrg = mk3(0, 0, 0), sDir = mk3(0, 0, 0);
     uint32_t reverseBits = 0;
 
     if (phase == PH_START) {
@@ -237,10 +256,10 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         }
     } else if (phase == PH_WAIT_PRIMARY) {
         // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
-        float4 ha = A.hitA[gs];
+        float4 ha = nt_load4(&A.hitA[gs]);
         uint2 hb = A.hitB[gs];
-        float4 s6 = A.S6[gs]; // the primary ray's direction
-        Vec3 pdir = mk3(s6.x, s6.y, s6.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+        float4 s2 = nt_load4(&A.S2[gs]); // the primary ray's direction
+        Vec3 pdir = mk3(s2.x, s2.y, s2.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
         DevHit h{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
         bool isHit = h.t != -1.0f;
         Surf5 sv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
@@ -267,23 +286,24 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         result = mk3(0.0f, 0.0f, 0.0f);
         lightSet = 0;
         depth = 0;
+        alive0 = alive;
         if (alive != 0u && depth < maxDepth) needBounce = true;
         else needEnd = true;
     } else if (phase == PH_WAIT_BOUNCE) {
-        float4 s0 = A.S0[gs], s1 = A.S1[gs], s2 = A.S2[gs], s3 = A.S3[gs], s4 = A.S4[gs], s5 = A.S5[gs], s6 = A.S6[gs];
-        pos = mk3(s0.x, s0.y, s0.z);
-        rayDir = mk3(s0.w, s1.x, s1.y);
-        normal = mk3(s1.z, s1.w, s2.x);
-        props.normal = mk3(s2.y, s2.z, s2.w);
-        props.uv = Vec2{s3.x, s3.y};
-        props.mat = asu(s3.z);
-        props.prim = asu(s3.w);
-        beta = mk3(s4.x, s4.y, s4.z);
-        material = asu(s4.w) & 0xffffffu;
-        lightSet = (asu(s4.w) >> 24) & 1u;
-        result = mk3(s5.x, s5.y, s5.z);
-        sflags = asu(s5.w);
-        ndir = mk3(s6.x, s6.y, s6.z);
+        uint32_t pmat = 0;
+        if (slot < alive) { // dead slots carry nothing
+            float4 s0 = nt_load4(&A.S0[gs]), s1 = nt_load4(&A.S1[gs]), s2 = nt_load4(&A.S2[gs]), s3 = nt_load4(&A.S3[gs]);
+            pos = mk3(s0.x, s0.y, s0.z);
+            pmat = asu(s0.w);
+            normal = mk3(s1.x, s1.y, s1.z);
+            sflags = asu(s1.w);
+            ndir = mk3(s2.x, s2.y, s2.z);
+            beta = mk3(s3.x, s3.y, s3.z);
+            float4 s4 = nt_load4(&A.S4[gs]);
+            result = mk3(s4.x, s4.y, s4.z);
+        }
+        props.mat = pmat;
+        lightSet = (sflags & SLOT_LIGHT_SET) ? 1u : 0u;
         // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
         if (sflags & SLOT_HAS_SHADOW) {
             if (A.occl[gs] == 0u) {
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         Surface ns{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
         Vec3 npos = mk3(0, 0, 0);
         if (sflags & SLOT_SURVIVE) {
-            float4 ha = A.hitA[gs];
+            float4 ha = nt_load4(&A.hitA[gs]);
             uint2 hb = A.hitB[gs];
             DevHit nh{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
             if (nh.t != -1.0f) {
@@ -386,10 +406,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         const bool directLighting = group_ballot(wantLight, gbase) != 0u;
         sflags = 0;
         if (directLighting && active) { // :196-252: every alive path gets an occlusion ray
-            Vec3 lightDir = lightSet ? mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]) : mk3(0, 0, 0);
-            sOrg = add3(pos, scale3(kFar, lightDir));
-            sDir = mk3(-lightDir.x, -lightDir.y, -lightDir.z);
-            emitShadow = true;
+            emitShadow = true; // the occlusion kernels build org = pos + kFar*L, dir = -L from the slot's state
             shadowPacket = (alive & 0xfu) > 2u; // :198
             sflags |= SLOT_HAS_SHADOW;
             nRays++;
@@ -410,8 +427,6 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         }
         if (survive) {
             ndir = normalize3(nextDir); // :267
-            eOrg = pos;
-            eDir = ndir;
             emitScatter = true;
             sflags |= SLOT_SURVIVE;
             nRays++;
@@ -421,7 +436,12 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
 
     STAMP(2);
     if (needEnd) {
-        // ---- Σ result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71)
+        // ---- Σ result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71).  Slots whose path ended in an earlier
+        // iteration left their result in memory.
+        if (slot >= aliveAtEntry && slot < alive0 && phase == PH_WAIT_BOUNCE) {
+            float4 s4 = nt_load4(&A.S4[gs]);
+            result = mk3(s4.x, s4.y, s4.z);
+        }
         Vec3 res = mk3(0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (uint32_t l = 0; l < 8; l++) res = add3(res, sh3(result, gbase + l));
@@ -447,8 +467,6 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         Vec3 avgDir;
         camera_packet(cam, rng, x, y, slot, gbase, pr, avgDir);
         reverseBits = (avgDir.x < 0.0f ? 1u : 0u) | (avgDir.y < 0.0f ? 2u : 0u) | (avgDir.z < 0.0f ? 4u : 0u);
-        eOrg = pr.org;
-        eDir = pr.dir;
         ndir = pr.dir;
         emitPrimary = true;
         phase = PH_WAIT_PRIMARY;
@@ -480,29 +498,26 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         for (int q = 0; q < Q_COUNT; q++) {
             if (!want[q]) continue;
             uint32_t idx = shard * A.shardCap + blkBase[q] + waveOff[q] + rank[q];
-            const bool shadow = q >= Q_OCC_PACKET;
-            Vec3 o = shadow ? sOrg : eOrg, d = shadow ? sDir : eDir;
-            float maxT = (q == Q_PRIMARY) ? 100000.0f : (q == Q_SCATTER ? kFar : kFar - kEpsilon);
-            uint32_t bits = (q == Q_PRIMARY) ? (owner | (reverseBits << 26)) : owner;
-            A.qA[q][idx] = make_float4(o.x, o.y, o.z, d.x);
-            A.qB[q][idx] = make_float4(d.y, d.z, maxT, asf(bits));
+            uint32_t bits = owner | (q == Q_PRIMARY ? (reverseBits << 26) : 0u) | (q >= Q_OCC_PACKET ? (lightSet << 29) : 0u);
+            __builtin_nontemporal_store(bits, &A.qE[q][idx]);
         }
     }
 
     STAMP(4);
     // ---- store state
-    if (inRange && (info >> 20) != PH_DONE) {
-        if (phase == PH_WAIT_BOUNCE) {
-            A.S0[gs] = make_float4(pos.x, pos.y, pos.z, rayDir.x);
-            A.S1[gs] = make_float4(rayDir.y, rayDir.z, normal.x, normal.y);
-            A.S2[gs] = make_float4(normal.z, props.normal.x, props.normal.y, props.normal.z);
-            A.S3[gs] = make_float4(props.uv.x, props.uv.y, asf(props.mat), asf(props.prim));
-            A.S4[gs] = make_float4(beta.x, beta.y, beta.z, asf((material & 0xffffffu) | (lightSet << 24)));
-            A.S5[gs] = make_float4(result.x, result.y, result.z, asf(sflags));
+    if (inRange && ((info >> 20) & 0xfu) != PH_DONE) {
+        if (phase == PH_WAIT_BOUNCE && slot < alive) {
+            nt_store4(&A.S0[gs], make_float4(pos.x, pos.y, pos.z, asf(props.mat)));
+            nt_store4(&A.S1[gs], make_float4(normal.x, normal.y, normal.z, asf(sflags | (lightSet ? SLOT_LIGHT_SET : 0u))));
+            nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
+            nt_store4(&A.S3[gs], make_float4(beta.x, beta.y, beta.z, 0.0f));
         }
-        if (phase == PH_WAIT_BOUNCE || phase == PH_WAIT_PRIMARY) A.S6[gs] = make_float4(ndir.x, ndir.y, ndir.z, 0.0f);
+        // a slot's result is stored while the slot is alive and once more in the iteration its path ends
+        if (phase == PH_WAIT_BOUNCE && slot < (aliveAtEntry > alive ? aliveAtEntry : alive))
+            nt_store4(&A.S4[gs], make_float4(result.x, result.y, result.z, 0.0f));
+        if (phase == PH_WAIT_PRIMARY) nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
         if (slot == 0) {
-            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20);
+            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20) | ((alive0 & 0xfu) << 24);
             A.gRng[g] = rng;
             A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
         }
@@ -555,17 +570,22 @@ __global__ void init_groups_kernel(WfArgs A)
     A.gColor[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// Rays of one (sharded) queue, results to the owner slots.
+// Rays of one (sharded) queue.  An entry names the owner slot; the ray itself is rebuilt from the slot's state exactly as
+// the reference builds it (camera.cpp:64-66; path_tracer.cpp:209-211 / 236-238; :269-273).  Results go to the owner.
+template <int MODE>
 struct QueueSrc {
-    const float4* qa;
-    const float4* qb;
+    const uint32_t* qe;
     uint32_t shardCount[PRT_QSHARDS];
     uint32_t shardCap;
     uint32_t n;
     uint32_t* cur;
+    const float4* S0;
+    const float4* S2;
     float4* hitA;
     uint2* hitB;
     uint32_t* occl;
+    Vec3 camPos, lightDir;
+    float kFar;
     uint32_t owner; // of the lane's current ray
     __device__ __forceinline__ uint32_t count() const { return n; }
     __device__ __forceinline__ uint32_t* cursor() const { return cur; }
@@ -580,17 +600,30 @@ struct QueueSrc {
             base += next ? shardCap : 0u;
             if (!next) break;
         }
-        float4 ra = qa[base + v], rb = qb[base + v];
-        org = mk3(ra.x, ra.y, ra.z);
-        dir = mk3(ra.w, rb.x, rb.y);
-        maxT = rb.z;
-        uint32_t bits = asu(rb.w);
+        const uint32_t bits = __builtin_nontemporal_load(&qe[base + v]);
         owner = bits & 0x3ffffffu;
-        rev = bits >> 26;
+        rev = (bits >> 26) & 7u;
+        if (MODE == PRT_MODE_PACKET) {
+            float4 s2 = nt_load4(&S2[owner]);
+            org = camPos;
+            dir = mk3(s2.x, s2.y, s2.z);
+            maxT = 100000.0f; // camera.cpp:64
+        } else if (MODE == PRT_MODE_SINGLE) {
+            float4 s0 = nt_load4(&S0[owner]), s2 = nt_load4(&S2[owner]);
+            org = mk3(s0.x, s0.y, s0.z);
+            dir = mk3(s2.x, s2.y, s2.z);
+            maxT = kFar; // path_tracer.cpp:270
+        } else {
+            float4 s0 = nt_load4(&S0[owner]);
+            Vec3 L = ((bits >> 29) & 1u) ? lightDir : mk3(0.0f, 0.0f, 0.0f);
+            org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
+            dir = mk3(-L.x, -L.y, -L.z);
+            maxT = kFar - 0.0008f; // :209, 236
+        }
     }
     __device__ __forceinline__ void store_hit(uint32_t, const DevHit& h) const
     {
-        hitA[owner] = make_float4(h.t, h.i, h.j, h.k);
+        nt_store4(&hitA[owner], make_float4(h.t, h.i, h.j, h.k));
         hitB[owner] = make_uint2(h.primId, h.meshId);
     }
     __device__ __forceinline__ void store_occ(uint32_t, bool occ) const { occl[owner] = occ ? 1u : 0u; }
@@ -604,9 +637,8 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? PRT_STACK_LDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
-    QueueSrc src;
-    src.qa = A.qA[MODE];
-    src.qb = A.qB[MODE];
+    QueueSrc<MODE> src;
+    src.qe = A.qE[MODE];
     src.n = 0;
 #pragma unroll
     for (int k = 0; k < PRT_QSHARDS; k++) {
@@ -615,6 +647,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     }
     src.shardCap = A.shardCap;
     src.cur = &A.qWork[MODE];
+    src.S0 = A.S0;
+    src.S2 = A.S2;
+    src.camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
+    src.lightDir = mk3(A.sc.lightDir[0], A.sc.lightDir[1], A.sc.lightDir[2]);
+    src.kFar = 2.0f * A.sc.radius; // path_tracer.cpp:192
     src.hitA = A.hitA;
     src.hitB = A.hitB;
     src.occl = A.occl;
@@ -1128,9 +1165,11 @@ static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
     const size_t slots = (size_t)groups * 8;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t need = 0;
+    const size_t qEntries = slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK;
     need += 3 * al(groups * sizeof(uint32_t)) + al(groups * sizeof(float4));
-    need += 7 * al(slots * sizeof(float4)) + al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t));
-    need += 2 * Q_COUNT * al((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
+    need += 5 * al(slots * sizeof(float4));                                                        // S0..S4
+    need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t)); // hits, occlusion
+    need += Q_COUNT * al(qEntries * sizeof(uint32_t));
     if (need > c->wfBytes) {
         if (c->wfBuffer) (void)hipFree(c->wfBuffer);
         c->wfBuffer = nullptr;
@@ -1144,15 +1183,15 @@ static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
     A.gInfo = (uint32_t*)take(groups * sizeof(uint32_t));
     A.gPixel = (uint32_t*)take(groups * sizeof(uint32_t));
     A.gColor = (float4*)take(groups * sizeof(float4));
-    float4** S[7] = {&A.S0, &A.S1, &A.S2, &A.S3, &A.S4, &A.S5, &A.S6};
-    for (auto ptr : S) *ptr = (float4*)take(slots * sizeof(float4));
+    A.S0 = (float4*)take(slots * sizeof(float4));
+    A.S1 = (float4*)take(slots * sizeof(float4));
+    A.S2 = (float4*)take(slots * sizeof(float4));
+    A.S3 = (float4*)take(slots * sizeof(float4));
+    A.S4 = (float4*)take(slots * sizeof(float4));
     A.hitA = (float4*)take(slots * sizeof(float4));
     A.hitB = (uint2*)take(slots * sizeof(uint2));
     A.occl = (uint32_t*)take(slots * sizeof(uint32_t));
-    for (int q = 0; q < Q_COUNT; q++) {
-        A.qA[q] = (float4*)take((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
-        A.qB[q] = (float4*)take((slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK) * sizeof(float4));
-    }
+    for (int q = 0; q < Q_COUNT; q++) A.qE[q] = (uint32_t*)take(qEntries * sizeof(uint32_t));
     return PRT_HIP_OK;
 }
 
