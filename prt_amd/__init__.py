@@ -468,3 +468,21 @@ def setup_atrium_standin(width, height, tris=262000, seed=1, alpha=True, bump=Tr
         scene.set_directional_light(_normalize((0.05, 1.0, 0.1)), (16.7, 15.6, 11.7))
     camera = Camera().create((-15.0, 4.0, 0.5), (1.0, 0.08, -0.05), width, height)
     return scene, camera, 1.0
+
+
+# ----------------------------------------------------------------------------- multi-GPU sharding (one process per GPU)
+def owned_pixel_mask(width, height, rank, nranks, tile=16):
+    """Boolean (height, width) mask of the pixels rank `rank` renders: 16x16 tiles (main.cpp:123-124) dealt round-robin,
+    tile id = ty * tiles_per_row + tx, owner = id % nranks -- the rule prt_hip_render applies on the device."""
+    ty, tx = np.meshgrid(np.arange(height) // tile, np.arange(width) // tile, indexing="ij")
+    tiles_x = (width + tile - 1) // tile
+    return ((ty * tiles_x + tx) % nranks) == rank
+
+
+def gather_image(framebuffer, dst=0):
+    """The path's only exchange: assemble the image on rank `dst`.  Every pixel is non-zero on exactly one rank (the
+    others never touch it in their zero-initialised framebuffer), so a sum-reduce reproduces it exactly (x + 0 == x).
+    `framebuffer` is a torch tensor (CUDA -> RCCL over xGMI with backend "nccl"; CPU -> gloo in the tests)."""
+    import torch.distributed as dist
+    dist.reduce(framebuffer, dst=dst, op=dist.ReduceOp.SUM)
+    return framebuffer

@@ -1,0 +1,69 @@
+"""world_size-2 test of the multi-GPU host path on CPU (gloo): tile ownership + the image gather.  The kernels cannot
+run here, so each rank fills its own tiles with the ORACLE's pixels (the checker standing in for the GPU), exactly as
+bench.py's ranks fill theirs with prt_hip_render(rank, nranks); rank 0 must end up with the single-rank image bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import prt_amd
+    import prt_testlib as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, spp = 72, 40, 8  # not multiples of the tile size
+    scene = T.OracleScene(T.cornell_scene(W, H, with_teapot=False))
+    own = prt_amd.owned_pixel_mask(W, H, rank, world)
+    fb = np.zeros((H, W, 3), dtype=np.float32)
+    for ty in range(0, H, 16):
+        for tx in range(0, W, 16):
+            if own[ty, tx]:
+                x1, y1 = min(tx + 15, W - 1), min(ty + 15, H - 1)
+                crop, _ = scene.trace_block(tx, ty, x1, y1, spp)
+                fb[ty:y1 + 1, tx:x1 + 1] = crop
+    assert (fb[~own] == 0).all()
+    t = torch.from_numpy(fb)
+    prt_amd.gather_image(t, dst=0)
+    # every pixel has exactly one owner
+    cover = torch.from_numpy(own.astype(np.int32))
+    dist.all_reduce(cover)
+    assert (cover == 1).all()
+    if rank == 0:
+        full, _ = scene.render(spp)
+        np.save(out_path, np.stack([t.numpy(), full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_sharding_and_gather(tmp_path):
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got, ref = np.load(out)
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_owned_pixel_mask_partitions_the_image():
+    import prt_amd
+    for (w, h, n) in ((1920, 1080, 8), (100, 52, 3), (16, 16, 2), (17, 1, 4)):
+        total = sum(prt_amd.owned_pixel_mask(w, h, r, n).astype(np.int64) for r in range(n))
+        assert (total == 1).all()
+        counts = [int(prt_amd.owned_pixel_mask(w, h, r, n).sum()) for r in range(n)]
+        if w * h >= 16 * 16 * n * 4:
+            assert max(counts) - min(counts) <= 4 * 256  # round-robin keeps the shares within a few tiles
