@@ -144,9 +144,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
 
     setup, kw, W, H, spp, depth, describe = WORKLOADS[args.workload]
     W, H = args.width or W, args.height or H
@@ -166,13 +169,13 @@ def main():
 
     def step():
         tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure, rank=rank, nranks=world)
-        if world > 1:
+        if use_dist:
             # the only exchange: image gather.  Every pixel is non-zero on exactly one rank, so a sum-reduce to rank 0
             # assembles the image exactly (x + 0 == x); 25 MB at 1080p over xGMI.
             prt_amd.gather_image(fb, dst=0)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,7 +191,7 @@ def main():
     st = tracer.stats()
     t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
     rays = torch.tensor([st["raysTraced"], st["occludedTraced"]], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     dt = float(t_all.item())
@@ -226,7 +229,7 @@ def main():
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     tracer.close()

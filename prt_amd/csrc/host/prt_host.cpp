@@ -18,6 +18,17 @@ namespace prt
 
 void logPrintf(LogLevel level, const char* format...)
 {
+    // kVerbose lines (the reference prints BVH statistics and load messages, log.cpp:10-25) go to stderr and only when
+    // PRT_VERBOSE is set, so that a host's stdout stays its own
+    static const bool verbose = getenv("PRT_VERBOSE") != nullptr;
+    if (level == LogLevel::kVerbose) {
+        if (!verbose) return;
+        va_list args;
+        va_start(args, format);
+        vfprintf(stderr, format, args);
+        va_end(args);
+        return;
+    }
     if (level == LogLevel::kError) printf("ERROR: ");
     va_list args;
     va_start(args, format);

@@ -617,14 +617,18 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
     const uint32_t totalWaves = gridDim.x * (PRT_BLOCK / 64);
     uint32_t chunk = n / (totalWaves * 4u);
     chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
-    uint32_t rangeNext = 0, rangeEnd = 0;
+    if (n == 0u) return;
+    // every wave starts on its own static range (no atomic); the shared cursor hands out what lies beyond them
+    const uint32_t waveId = blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t staticEnd = totalWaves * chunk;
+    uint32_t rangeNext = waveId * chunk, rangeEnd = rangeNext + chunk;
     for (;;) {
         unsigned long long need = __ballot(!active && !exhausted);
         if (need) {
             const uint32_t k = (uint32_t)__popcll(need), avail = rangeEnd - rangeNext;
             uint32_t newBase = 0;
             if (avail < k) { // wave-uniform
-                if (lane == 0) newBase = atomicAdd(src.cursor(), chunk);
+                if (lane == 0) newBase = staticEnd + atomicAdd(src.cursor(), chunk);
                 newBase = (uint32_t)__shfl((int)newBase, 0, 64);
             }
             if (!active && !exhausted) {
