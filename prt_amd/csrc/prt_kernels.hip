@@ -125,6 +125,8 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
+#define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
+#define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
 #define SLOT_LIGHT_SET 4u
@@ -195,10 +197,10 @@ struct WfArgs {
 #endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
+__global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
 {
 #ifdef PRT_STAMP
-    unsigned long long stampAcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stampAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t tid = threadIdx.x;
@@ -304,6 +306,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
         }
         props.mat = pmat;
         lightSet = (sflags & SLOT_LIGHT_SET) ? 1u : 0u;
+#ifdef PRT_STAMP
+        asm volatile("" ::"v"(pos.x), "v"(beta.x), "v"(result.x));
+        __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the state loads have landed
+#endif
+        STAMP(6);
         // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
         if (sflags & SLOT_HAS_SHADOW) {
             if (A.occl[gs] == 0u) {
@@ -327,6 +334,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
                 npos = add3(scale3(nh.t, ndir), pos);
             }
         }
+#ifdef PRT_STAMP
+        asm volatile("" ::"v"(npos.x), "v"(ns.normal.x));
+        __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+        STAMP(7);
         uint32_t nm = group_ballot(hitNext, gbase);
         uint32_t nAlive = __popc(nm);
         if (nAlive == 0u) {
@@ -348,6 +360,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
                 float q = std_max(0.05f, 1.0f - length3(beta));
                 betaNew = div3s(beta, 1.0f - q);
             }
+#ifdef PRT_STAMP
+            asm volatile("" ::"v"(snorm.x));
+            __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+            STAMP(8);
             uint32_t src2 = gbase + ((slot < nAlive) ? nth_set(nm, slot) : slot);
             props.normal = sh3(nv.normal, src2);
             props.uv = Vec2{shf(nv.uv.x, src2), shf(nv.uv.y, src2)};
@@ -387,6 +404,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
             if (j == pre + 1u) r1b = s;
         }
         rng = s;
+        STAMP(9);
         Vec3 nextDir = mk3(0, 0, 0);
         bool wantLight = false;
         if (draws) {
@@ -403,6 +421,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
                 nextDir = add3(scale3(0.9f, reflectDir), scale3(0.1f, dd));
             }
         }
+#ifdef PRT_STAMP
+        asm volatile("" ::"v"(nextDir.x), "v"(beta.x));
+        __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+        STAMP(10);
         const bool directLighting = group_ballot(wantLight, gbase) != 0u;
         sflags = 0;
         if (directLighting && active) { // :196-252: every alive path gets an occlusion ray
@@ -490,9 +513,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
             waveOff[q] = shu(off, 0);
         }
         __syncthreads();
+        STAMP(11);
         const uint32_t shard = blockIdx.x % PRT_QSHARDS;
         if (tid < Q_COUNT && blkCount[tid] != 0u) blkBase[tid] = atomicAdd(&A.qWork[4 + tid * PRT_QSHARDS + shard], blkCount[tid]);
         __syncthreads();
+        STAMP(12);
         const uint32_t owner = gs;
 #pragma unroll
         for (int q = 0; q < Q_COUNT; q++) {
@@ -525,20 +550,28 @@ __global__ __launch_bounds__(PRT_BLOCK) void shade_kernel(WfArgs A)
     STAMP(5);
 #ifdef PRT_STAMP
     if (lane == 0)
-        for (int k = 0; k < 6; k++) atomicAdd(&A.counters[8 + k], stampAcc[k]);
-    if (lane == 0) atomicAdd(&A.counters[15], 1ull);
+        for (int k = 0; k < 13; k++) atomicAdd(&A.counters[8 + k], stampAcc[k]);
+    if (lane == 0) atomicAdd(&A.counters[23], 1ull);
 #endif
-    // ---- statistics: one atomic per wave and counter (per-lane atomics on one address would serialise the launch)
+    // ---- statistics: block-level sums in LDS, then one atomic per block and counter on one of PRT_STAT_SHARDS copies
+    // (per-wave atomics on ONE address would be ~0.5 M same-address atomics per launch; they serialise at the memory side)
     {
-        unsigned long long* C = A.counters;
+        __shared__ uint32_t blkStat[5];
+        if (tid < 5) blkStat[tid] = 0;
+        __syncthreads();
         uint32_t r = wave_sum((uint32_t)nRays), o = wave_sum((uint32_t)nOccl), px = wave_sum((uint32_t)nPx);
         uint32_t nh = COUNT ? wave_sum(tr.nHit) : 0u, nt = COUNT ? wave_sum(tr.nTap) : 0u;
         if (lane == 0) {
-            if (r) atomicAdd(&C[0], (unsigned long long)r);
-            if (o) atomicAdd(&C[1], (unsigned long long)o);
-            if (nh) atomicAdd(&C[4], (unsigned long long)nh);
-            if (nt) atomicAdd(&C[5], (unsigned long long)nt);
-            if (px) atomicAdd(&C[6], (unsigned long long)px);
+            if (r) atomicAdd(&blkStat[0], r);
+            if (o) atomicAdd(&blkStat[1], o);
+            if (nh) atomicAdd(&blkStat[2], nh);
+            if (nt) atomicAdd(&blkStat[3], nt);
+            if (px) atomicAdd(&blkStat[4], px);
+        }
+        __syncthreads();
+        if (tid < 5 && blkStat[tid] != 0u) {
+            const int slotOf[5] = {0, 1, 4, 5, 6};
+            atomicAdd(&A.counters[(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE + slotOf[tid]], (unsigned long long)blkStat[tid]);
         }
     }
 }
@@ -925,8 +958,8 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipMalloc(&c->work, 1024));
     HIP_TRY(hipMemset(c->work, 0, 1024));
-    HIP_TRY(hipMalloc(&c->counters, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     *out = c;
     return PRT_HIP_OK;
 }
@@ -1252,7 +1285,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     const uint32_t passGroups = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(totalWork, 1), kMaxGroupsPerPass);
     if ((rc = wf_layout(c, passGroups, A))) return rc;
 
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
     if (c->eventsUsed == c->events.size()) {
         hipEvent_t a = nullptr, b = nullptr;
         HIP_TRY(hipEventCreate(&a));
@@ -1303,12 +1336,21 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     if (!c || !st) return fail(PRT_HIP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long h[16];
-    HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long h[PRT_STAT_STRIDE] = {0};
+    {
+        std::vector<unsigned long long> all((size_t)PRT_STAT_SHARDS * PRT_STAT_STRIDE);
+        HIP_TRY(hipMemcpy(all.data(), c->counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int sh = 0; sh < PRT_STAT_SHARDS; sh++)
+            for (int k = 0; k < PRT_STAT_STRIDE; k++) h[k] += all[(size_t)sh * PRT_STAT_STRIDE + k];
+    }
 #ifdef PRT_STAMP
-    fprintf(stderr, "shade stamps (avg cycles per wave): load %.0f consume %.0f bounce %.0f end+camera %.0f emit %.0f store %.0f  waves %llu\n",
-            (double)h[8] / h[15], (double)h[9] / h[15], (double)h[10] / h[15], (double)h[11] / h[15], (double)h[12] / h[15],
-            (double)h[13] / h[15], h[15]);
+    {
+        const char* names[13] = {"header", "consume-rest", "bounce-rest", "end+camera", "emit-writes", "store", "state-loads", "hit+surface",
+                                 "bump", "mats+rng", "diffuse", "emit-sync1", "emit-sync2"};
+        fprintf(stderr, "shade stamps (avg cycles per wave, %llu waves):", h[23]);
+        for (int k = 0; k < 13; k++) fprintf(stderr, " %s %.0f", names[k], (double)h[8 + k] / (double)(h[23] ? h[23] : 1));
+        fprintf(stderr, "\n");
+    }
 #endif
     st->raysTraced = h[0];
     st->occludedTraced = h[1];
@@ -1350,7 +1392,7 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     HIP_TRY(hipMalloc(&dh, (size_t)n * sizeof(prt_hit)));
     HIP_TRY(hipMemcpy(dorg, org, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ddir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMemsetAsync(c->work, 0, 1024, c->stream));
     RaysArgs A{c->sc, n, dorg, ddir, maxT, dh, c->work, c->spill, c->spillThreads, c->counters};
     blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
