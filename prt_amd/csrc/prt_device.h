@@ -15,6 +15,9 @@
 #define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (reference + entry distance: 8 B each)
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
+#ifndef PRT_LEAF_BREAK
+#define PRT_LEAF_BREAK 28 // lanes waiting on a leaf that end the node phase early
+#endif
 
 // ---------------------------------------------------------------------------- device scene
 // wnodes: 4 x float4 (64 B) per INTERNAL node: {lo0.xyz hi0.x} {hi0.yz lo1.xy} {lo1.z hi1.xyz} {ref0 ref1 splitAxis 0}
@@ -664,8 +667,15 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                 active = false;
             }
         }
-        while (__any(active && ref_is_internal(T.ref))) {
-            if (active && ref_is_internal(T.ref)) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+        // Node phase: lanes on internal nodes step together.  It ends when no lane is on an internal node -- or, sooner, when
+        // enough lanes are waiting on a leaf (PRT_LEAF_BREAK): a few long descents (every freshly fetched ray starts at the
+        // root) must not keep the rest of the wave idle.
+        for (;;) {
+            const bool onNode = active && ref_is_internal(T.ref);
+            const unsigned long long nodeMask = __ballot(onNode);
+            if (nodeMask == 0ull) break;
+            if ((uint32_t)__popcll(__ballot(active && ref_is_leaf(T.ref))) >= PRT_LEAF_BREAK) break;
+            if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
         }
         if (active && ref_is_leaf(T.ref)) tracer_leaf<MODE, COUNT>(sc, T, st, tr);
     }
