@@ -525,6 +525,62 @@ __device__ __forceinline__ bool tracer_next_bvh(const DevScene& sc, Tracer& T, T
     }
 }
 
+// The per-mode decision at an internal node for a NaN-free ray, from the slab extents of both children (max_t0, min_t1):
+// every box test of the reference is a function of those two numbers when no NaN is involved.
+struct NodeExt {
+    float mx0, mn0, mx1, mn1;
+};
+
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void tracer_decide(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr, const WideNode& w, const NodeExt& e)
+{
+    const float inf = __builtin_inff();
+    if (MODE == PRT_MODE_SINGLE) {
+        if (COUNT) tr.nBox += 2;
+        float t0 = (e.mn0 < e.mx0) ? inf : e.mx0, t1 = (e.mn1 < e.mx1) ? inf : e.mx1; // vecmath.h:1420-1424
+        bool h0 = t0 < T.hit.t, h1 = t1 < T.hit.t;
+        if (h0 && h1) {
+            bool near0 = t0 < t1;
+            st.put(T.sp++, near0 ? w.ref1 : w.ref0);
+            T.ref = near0 ? w.ref0 : w.ref1;
+        } else if (h0) {
+            T.ref = w.ref0;
+        } else if (h1) {
+            T.ref = w.ref1;
+        } else {
+            T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+        }
+    } else if (MODE == PRT_MODE_PACKET) {
+        if (COUNT) tr.nBox += 2;
+        float e0 = (e.mn0 >= e.mx0) ? e.mx0 : inf, e1 = (e.mn1 >= e.mx1) ? e.mx1 : inf; // vecmath.h:1515-1517
+        bool rev = (T.rev >> (w.axis & 3u)) & 1u;
+        uint32_t firstRef = rev ? w.ref1 : w.ref0, laterRef = rev ? w.ref0 : w.ref1;
+        float firstE = rev ? e1 : e0, laterE = rev ? e0 : e1;
+        if (laterE < T.hit.t) st.putT(T.sp++, laterRef, laterE);
+        if (firstE < T.hit.t) T.ref = firstRef;
+        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+    } else {
+        bool h0, h1;
+        if (MODE == PRT_MODE_OCC_PACKET) {
+            h0 = ((e.mn0 >= e.mx0) ? e.mx0 : inf) < T.maxT;
+            h1 = ((e.mn1 >= e.mx1) ? e.mx1 : inf) < T.maxT;
+        } else { // vecmath.h:1449-1466: the 4th SSE lane carries (-FLT_MAX, maxT)
+            const float lowest = -3.402823466e+38f;
+            float w0 = sse_min(lowest, T.maxT), w1 = sse_max(lowest, T.maxT);
+            h0 = __builtin_fminf(e.mn0, w1) > __builtin_fmaxf(e.mx0, w0);
+            h1 = __builtin_fminf(e.mn1, w1) > __builtin_fmaxf(e.mx1, w0);
+        }
+        if (COUNT) {
+            st.put(T.sp++, h1 ? w.ref1 : PRT_REF_DEAD);
+            tr.nBox++;
+        } else if (h1) {
+            st.put(T.sp++, w.ref1);
+        }
+        if (h0) T.ref = w.ref0;
+        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+    }
+}
+
 // One internal node: fetch its 64-byte record, test both children, choose where to go.
 template <int MODE, bool COUNT>
 __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr, uint32_t& overflow)
@@ -536,6 +592,18 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
         T.ref = PRT_REF_NONE;
         T.sp = 0;
         T.m = sc.bvhCount;
+        return;
+    }
+    if (T.r.fast) { // one straight-line block: 12 slabs, two min3/max3 pairs
+        float a0[3], a1[3], b0[3], b1[3];
+        slabs<true>(w.b0, T.r, a0, a1);
+        slabs<true>(w.b1, T.r, b0, b1);
+        NodeExt e;
+        e.mx0 = __builtin_fmaxf(__builtin_fmaxf(a0[0], a0[1]), a0[2]);
+        e.mn0 = __builtin_fminf(__builtin_fminf(a1[0], a1[1]), a1[2]);
+        e.mx1 = __builtin_fmaxf(__builtin_fmaxf(b0[0], b0[1]), b0[2]);
+        e.mn1 = __builtin_fminf(__builtin_fminf(b1[0], b1[1]), b1[2]);
+        tracer_decide<MODE, COUNT>(sc, T, st, tr, w, e);
         return;
     }
     if (MODE == PRT_MODE_SINGLE) {
