@@ -266,3 +266,122 @@ def test_full_size_c2_properties(tracer):
     for (x0, y0) in ((496, 600), (200, 300), (0, 0), (1008, 1008)):
         ref, _ = s.trace_block(x0, y0, x0 + 15, y0 + 15, 64)
         assert_bits_equal(a[y0:y0 + 16, x0:x0 + 16], ref, f"tile at {(x0, y0)}")
+
+
+# ----------------------------------------------------------------------------- stack spill, overflow, large scenes, two passes
+def _geometric_soup(kmax):
+    """Triangles at x = 2^k: binned SAH peels them off a few at a time, giving a tree about kmax/2 deep."""
+    tris = []
+    for k in range(kmax):
+        x = np.float32(2.0) ** k
+        s = x * np.float32(0.25)
+        tris.append([[x, -s, -s], [x, s, -s], [x, 0, s]])
+    pos = np.asarray(tris, dtype=np.float32).reshape(-1, 3)
+    idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+    mats = np.array([T.make_material(diffuse=(0.5, 0.5, 0.5))], dtype=T.MATERIAL_DTYPE)
+    return idx, pos, np.zeros(len(idx), dtype=np.uint32), mats
+
+
+def _tree_depth(nodes):
+    depth, stack = 0, [(0, 1)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        if nodes["primCount"][i] == 0xF:
+            stack.append((i + 1, d + 1))
+            stack.append((int(nodes["primOrSecondNodeIndex"][i]), d + 1))
+    return depth
+
+
+def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer):
+    """A tree deeper than the 16 stack entries kept in LDS (the rest of the 64 spill to HBM)."""
+    idx, pos, pm, mats = _geometric_soup(56)
+    scene = prt_amd.Scene()
+    scene.add(prt_amd.Mesh.from_arrays(idx, pos, pm, mats.view(prt_amd.MATERIAL_DTYPE)))
+    camera = prt_amd.Camera().create((-4, 0, 0), (1, 0, 0), 32, 32)
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera)
+    assert 17 < _tree_depth(desc.product_arrays["meshes"][0]["nodes"]) < 60  # deeper than the 16 LDS entries
+    s = T.OracleScene(desc)
+    rng = np.random.default_rng(1)
+    n = 1024
+    org = np.zeros((n, 3), dtype=np.float32)
+    org[:, 0] = -3
+    org[:, 1:] = rng.uniform(-0.2, 0.2, (n, 2))
+    d = np.zeros((n, 3), dtype=np.float32)
+    d[:, 0] = 1
+    d[:, 1:] = rng.uniform(-0.02, 0.02, (n, 2))
+    d[: n // 2, 0] = -1  # rays that leave the scene: every box behind the origin still passes the reference's test
+    org[: n // 2, 0] = np.float32(2.0) ** 57
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    far = float(np.float32(2.0) * np.float32(s.radius()))
+    os_, oc1 = s.intersect_single(org, d, far)
+    op, oc8 = s.intersect_packet(org, d, far)
+    assert tracer.trace_rays(0, org, d, far).tobytes() == os_.tobytes()
+    assert tracer.trace_rays(1, org, d, far).tobytes() == op.tobytes()
+    assert (tracer.trace_rays(2, org, d, far)["t"] == oc1).all()
+    assert (tracer.trace_rays(3, org, d, far)["t"] == oc8).all()
+    rgb = tracer.render(8)
+    ref, _ = s.render(8)
+    assert_bits_equal(rgb, ref, "deep-tree radiance")
+
+
+def test_stack_overflow_is_reported_like_the_reference_assert(tracer):
+    """The reference asserts when its 64-entry stack overflows (bvh.cpp:552, 627); the C-ABI returns PRT_HIP_ESTACK.
+    The binned-SAH builder does not produce such trees from sane input, so a hand-made chain BVH (every level pushes its
+    second child and descends into the first) is uploaded through the C-ABI descriptor."""
+    import ctypes as C
+    D = 80
+    n_nodes, n_prims = 2 * D + 1, D + 1
+    nodes = np.zeros(n_nodes, dtype=T.NODE_DTYPE)
+    nodes["lower"] = (-1e6, -1e6, -1e6)
+    nodes["upper"] = (1e6, 1e6, 1e6)
+    for i in range(D):
+        nodes["primCount"][i] = 0xF
+        nodes["primOrSecondNodeIndex"][i] = 2 * D - i
+    for k in range(n_prims):  # leaves in DFS order hold triangle k
+        nodes["primCount"][D + k] = 1
+        nodes["primOrSecondNodeIndex"][D + k] = k
+        nodes["triVectorIndex"][D + k] = k
+    pos = np.zeros((3 * n_prims, 3), dtype=np.float32)
+    for k in range(n_prims):
+        pos[3 * k:3 * k + 3] = [[5000 + k, 0, 0], [5000 + k, 1, 0], [5000 + k, 0, 1]]
+    idx = np.arange(3 * n_prims, dtype=np.uint32)
+    remap = np.arange(n_prims, dtype=np.uint32)
+    pm = np.zeros(n_prims, dtype=np.uint32)
+    mats = np.array([T.make_material(diffuse=(0.5, 0.5, 0.5))], dtype=T.MATERIAL_DTYPE)
+    md = prt_amd.MeshDesc()
+    md.nodeCount, md.nodes = n_nodes, nodes.ctypes.data_as(C.POINTER(prt_amd.BvhNode))
+    md.primCount, md.primRemapping = n_prims, remap.ctypes.data_as(C.POINTER(C.c_uint32))
+    md.vertexCount, md.indices = 3 * n_prims, idx.ctypes.data_as(C.POINTER(C.c_uint32))
+    md.positions = pos.ctypes.data_as(C.POINTER(C.c_float))
+    md.materialCount, md.primMaterial = 1, pm.ctypes.data_as(C.POINTER(C.c_uint32))
+    md.materials = mats.ctypes.data_as(C.POINTER(prt_amd.Material))
+    sd = prt_amd.SceneDesc()
+    sd.meshCount, sd.meshes, sd.radius = 1, C.pointer(md), 1e4
+    prt_amd._check(prt_amd.lib().prt_hip_upload_scene(tracer._ctx, C.byref(sd)), "upload")
+    org = np.tile(np.array([[0.0, 0.2, 0.2]], dtype=np.float32), (8, 1))
+    d = np.tile(np.array([[1.0, 0, 0]], dtype=np.float32), (8, 1))
+    for mode in (0, 1, 2, 3):
+        tracer.trace_rays(mode, org, d, 100.0)
+        if mode == 0:
+            tracer.stats()  # near-first single traversal pops as it goes on this chain: no overflow
+            continue
+        with pytest.raises(prt_amd.PrtError, match="64 stack entries"):
+            tracer.stats()
+
+
+def test_large_scene_4k_two_passes_matches_oracle_tiles(tracer):
+    """C5-class at its BASELINE resolution: 3840x2160 (8.3 M pixel groups = two wavefront passes), a 1 M-triangle emissive
+    scene without directional light, depth cap 12, exposure 64; 8 spp to keep the oracle side short.  Sample tiles
+    from both passes must match the oracle bit for bit."""
+    scene, camera, _ = prt_amd.setup_atrium_standin(3840, 2160, tris=1000000, emissive_fraction=0.25, light=False)
+    upload(tracer, scene, camera)
+    img = tracer.render(8, max_depth=12, exposure=64.0)
+    st = tracer.stats()
+    assert st["nPx"] == 3840 * 2160 and st["stackOverflow"] == 0
+    desc = T.scene_desc_from_product(scene, camera, 64.0)
+    s = T.OracleScene(desc)
+    for (x0, y0) in ((0, 0), (1904, 1072), (3824, 2144), (640, 1600)):
+        ref, _ = s.trace_block(x0, y0, x0 + 15, y0 + 15, 8, max_depth=12)
+        assert_bits_equal(img[y0:y0 + 16, x0:x0 + 16], ref, f"4K tile at {(x0, y0)}")
