@@ -370,7 +370,7 @@ class PathTracer:
         W, H = self._camera.width, self._camera.height
         img = np.zeros((H, W, 3), dtype=np.float32)
         _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
-        self.stats()  # raises on stack overflow
+        self.last_stats = self.stats()  # raises on stack overflow
         return img[y0:y1 + 1, x0:x1 + 1].copy()
 
     def render(self, samples, **kw):

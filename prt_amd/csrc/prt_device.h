@@ -20,7 +20,8 @@
 #endif
 
 // ---------------------------------------------------------------------------- device scene
-// wnodes: 4 x float4 (64 B) per INTERNAL node: {lo0.xyz hi0.x} {hi0.yz lo1.xy} {lo1.z hi1.xyz} {ref0 ref1 splitAxis 0}
+// wnodes: 4 x float4 (64 B) per INTERNAL node, (lo, hi) pairs per axis so that the slab arithmetic runs on packed
+//         f32 pairs: {lo0.x hi0.x lo0.y hi0.y} {lo0.z hi0.z lo1.z hi1.z} {lo1.x hi1.x lo1.y hi1.y} {ref0 ref1 splitAxis 0}
 //         child 0 is the reference's node i+1, child 1 its m_nodes[primOrSecondNodeIndex]; refs: see PRT_REF_LEAF
 // roots:  per BVH the root's reference and box (rootRef, rootBox)
 // tris:   3 x float4 per triangle in primRemapping order {p0 primId} {p1 alphaRef} {p2 0}
@@ -368,19 +369,23 @@ struct Stack {
     }
 };
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
 struct WideNode {
-    Box b0, b1;
+    float4 w0, w1, w2; // the three (lo, hi) pair records as stored
     uint32_t ref0, ref1, axis;
+    __device__ __forceinline__ Box box0() const { return Box{mk3(w0.x, w0.z, w1.x), mk3(w0.y, w0.w, w1.y)}; }
+    __device__ __forceinline__ Box box1() const { return Box{mk3(w2.x, w2.z, w1.z), mk3(w2.y, w2.w, w1.w)}; }
 };
 
 __device__ __forceinline__ void load_wide(const DevScene& sc, uint32_t idx, WideNode& w)
 {
     const float4* p = sc.wnodes + 4 * (size_t)idx;
-    float4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-    w.b0.lo = mk3(w0.x, w0.y, w0.z);
-    w.b0.hi = mk3(w0.w, w1.x, w1.y);
-    w.b1.lo = mk3(w1.z, w1.w, w2.x);
-    w.b1.hi = mk3(w2.y, w2.z, w2.w);
+    float4 w3;
+    w.w0 = p[0];
+    w.w1 = p[1];
+    w.w2 = p[2];
+    w3 = p[3];
     w.ref0 = asu(w3.x);
     w.ref1 = asu(w3.y);
     w.axis = asu(w3.z);
@@ -594,21 +599,23 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
         T.m = sc.bvhCount;
         return;
     }
-    if (T.r.fast) { // one straight-line block: 12 slabs, two min3/max3 pairs
-        float a0[3], a1[3], b0[3], b1[3];
-        slabs<true>(w.b0, T.r, a0, a1);
-        slabs<true>(w.b1, T.r, b0, b1);
+    if (T.r.fast) { // one straight-line block: six packed (lo, hi) slab pairs, two min3/max3 pairs
+        const DevRay& r = T.r;
+        const f2_t c0x = (f2_t{w.w0.x, w.w0.y} - r.org.x) * r.inv.x, c0y = (f2_t{w.w0.z, w.w0.w} - r.org.y) * r.inv.y;
+        const f2_t c0z = (f2_t{w.w1.x, w.w1.y} - r.org.z) * r.inv.z, c1z = (f2_t{w.w1.z, w.w1.w} - r.org.z) * r.inv.z;
+        const f2_t c1x = (f2_t{w.w2.x, w.w2.y} - r.org.x) * r.inv.x, c1y = (f2_t{w.w2.z, w.w2.w} - r.org.y) * r.inv.y;
         NodeExt e;
-        e.mx0 = __builtin_fmaxf(__builtin_fmaxf(a0[0], a0[1]), a0[2]);
-        e.mn0 = __builtin_fminf(__builtin_fminf(a1[0], a1[1]), a1[2]);
-        e.mx1 = __builtin_fmaxf(__builtin_fmaxf(b0[0], b0[1]), b0[2]);
-        e.mn1 = __builtin_fminf(__builtin_fminf(b1[0], b1[1]), b1[2]);
+        e.mx0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c0x.x, c0x.y), __builtin_fminf(c0y.x, c0y.y)), __builtin_fminf(c0z.x, c0z.y));
+        e.mn0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c0x.x, c0x.y), __builtin_fmaxf(c0y.x, c0y.y)), __builtin_fmaxf(c0z.x, c0z.y));
+        e.mx1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c1x.x, c1x.y), __builtin_fminf(c1y.x, c1y.y)), __builtin_fminf(c1z.x, c1z.y));
+        e.mn1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c1x.x, c1x.y), __builtin_fmaxf(c1y.x, c1y.y)), __builtin_fmaxf(c1z.x, c1z.y));
         tracer_decide<MODE, COUNT>(sc, T, st, tr, w, e);
         return;
     }
+    const Box wb0 = w.box0(), wb1 = w.box1();
     if (MODE == PRT_MODE_SINGLE) {
         if (COUNT) tr.nBox += 2;
-        float t0 = box_t(w.b0, T.r), t1 = box_t(w.b1, T.r);
+        float t0 = box_t(wb0, T.r), t1 = box_t(wb1, T.r);
         bool h0 = t0 < T.hit.t, h1 = t1 < T.hit.t;
         if (h0 && h1) {
             bool near0 = t0 < t1;
@@ -623,7 +630,7 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
         }
     } else if (MODE == PRT_MODE_PACKET) {
         if (COUNT) tr.nBox += 2; // the reference pops and tests both children
-        float e0 = box_soa_entry(w.b0, T.r), e1 = box_soa_entry(w.b1, T.r);
+        float e0 = box_soa_entry(wb0, T.r), e1 = box_soa_entry(wb1, T.r);
         bool rev = (T.rev >> (w.axis & 3u)) & 1u; // popped first = the second child when reverse
         uint32_t firstRef = rev ? w.ref1 : w.ref0, laterRef = rev ? w.ref0 : w.ref1;
         float firstE = rev ? e1 : e0, laterE = rev ? e0 : e1;
@@ -631,8 +638,8 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
         if (firstE < T.hit.t) T.ref = firstRef;
         else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
     } else {
-        bool h0 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(w.b0, T.r, T.maxT) : box_bool(w.b0, T.r, T.maxT);
-        bool h1 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(w.b1, T.r, T.maxT) : box_bool(w.b1, T.r, T.maxT);
+        bool h0 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(wb0, T.r, T.maxT) : box_bool(wb0, T.r, T.maxT);
+        bool h1 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(wb1, T.r, T.maxT) : box_bool(wb1, T.r, T.maxT);
         if (COUNT) {
             st.put(T.sp++, h1 ? w.ref1 : PRT_REF_DEAD);
             tr.nBox++; // child 0 is popped next

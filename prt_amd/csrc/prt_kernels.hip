@@ -1073,9 +1073,9 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                 if (n.primCount != 0xf) continue;
                 const prt_bvh_node& c0 = md.nodes[i + 1];
                 const prt_bvh_node& c1 = md.nodes[n.primOrSecondNodeIndex];
-                wnodes.push_back(make_float4(c0.lower[0], c0.lower[1], c0.lower[2], c0.upper[0]));
-                wnodes.push_back(make_float4(c0.upper[1], c0.upper[2], c1.lower[0], c1.lower[1]));
-                wnodes.push_back(make_float4(c1.lower[2], c1.upper[0], c1.upper[1], c1.upper[2]));
+                wnodes.push_back(make_float4(c0.lower[0], c0.upper[0], c0.lower[1], c0.upper[1])); // x and y of child 0
+                wnodes.push_back(make_float4(c0.lower[2], c0.upper[2], c1.lower[2], c1.upper[2])); // z of both children
+                wnodes.push_back(make_float4(c1.lower[0], c1.upper[0], c1.lower[1], c1.upper[1])); // x and y of child 1
                 wnodes.push_back(make_float4(ubits(refOf(i + 1)), ubits(refOf(n.primOrSecondNodeIndex)), ubits(n.splitAxis & 3u), 0.0f));
             }
             sc.rootRef[m] = refOf(0);
