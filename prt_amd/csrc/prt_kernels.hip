@@ -898,6 +898,8 @@ struct prt_hip_ctx {
     size_t fbPixels = 0;
     uint32_t* work = nullptr; // Q_COUNT queue counters
     unsigned long long* counters = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // the trace kernels that run beside the scatter kernel
+    hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
     void* wfBuffer = nullptr; // wavefront state + queues of one pass
     size_t wfBytes = 0;
     uint32_t wfGroups = 0;
@@ -919,15 +921,27 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
     return PRT_HIP_OK;
 }
 
+// One iteration.  The four trace kernels of an iteration are independent of each other: three run on auxiliary
+// streams beside the scatter kernel so that the tail of one persistent grid is filled by the next (each has its own
+// stack-spill area); the next shade kernel waits for all four.
 template <bool COUNT>
-static void wf_iteration(const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
+static void wf_iteration(prt_hip_ctx* c, const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
 {
     (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), s); // claim cursors + shard counts
     hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(shadeBlocks), dim3(PRT_BLOCK), 0, s, A);
-    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
+    (void)hipEventRecord(c->evFork, s);
+    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
+    WfArgs B = A;
+    for (int k = 0; k < 3; k++) {
+        (void)hipStreamWaitEvent(c->aux[k], c->evFork, 0);
+        B.spill = A.spill + (size_t)(k + 1) * spillWords;
+        if (k == 0) hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
+        else if (k == 1) hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
+        else hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
+        (void)hipEventRecord(c->evJoin[k], c->aux[k]);
+    }
     hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
+    for (int k = 0; k < 3; k++) (void)hipStreamWaitEvent(s, c->evJoin[k], 0);
 }
 
 extern "C" {
@@ -956,6 +970,11 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(hipStreamCreate(&c->aux[k]));
+        HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
+    }
     HIP_TRY(hipMalloc(&c->work, 1024));
     HIP_TRY(hipMemset(c->work, 0, 1024));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
@@ -986,6 +1005,11 @@ void prt_hip_destroy(prt_hip_ctx* c)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    for (int k = 0; k < 3; k++) {
+        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+        if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
+    }
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1176,7 +1200,8 @@ static int ensure_launch_resources(prt_hip_ctx* c, uint32_t blocks)
     if (threads > c->spillThreads) {
         if (c->spill) (void)hipFree(c->spill);
         c->spill = nullptr;
-        HIP_TRY(hipMalloc(&c->spill, (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
+        // four areas: one per concurrently running trace kernel
+        HIP_TRY(hipMalloc(&c->spill, 4 * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
         c->spillThreads = threads;
     }
     return PRT_HIP_OK;
@@ -1303,8 +1328,8 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         const uint32_t shadeBlocks = (uint32_t)(((uint64_t)A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
         A.shardCap = ((shadeBlocks + PRT_QSHARDS - 1) / PRT_QSHARDS) * PRT_BLOCK;
         for (uint32_t it = 0; it < iterations; it++) {
-            if (p->countTraffic) wf_iteration<true>(A, shadeBlocks, traceBlocks, s);
-            else wf_iteration<false>(A, shadeBlocks, traceBlocks, s);
+            if (p->countTraffic) wf_iteration<true>(c, A, shadeBlocks, traceBlocks, s);
+            else wf_iteration<false>(c, A, shadeBlocks, traceBlocks, s);
         }
     }
     hipError_t le = hipGetLastError();
