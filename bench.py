@@ -219,7 +219,7 @@ def main():
                        "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL sum-reduce image gather" if world > 1
                        else "one GPU", "device": name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "render_kernel<false>", "kernel_ms": kernel_ms,
+                         "traffic": None, "kernel": "wavefront pipeline of one frame: shade_kernel + trace_kernel<0..3>, (spp/8)*(1+depth)+1 iterations", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": int(B),
                          "events_per_launch": {k: ct[k] for k in ("nBox", "nTri", "nHit", "nTap", "nPx")}},
         }

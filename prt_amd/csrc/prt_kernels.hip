@@ -900,6 +900,7 @@ struct prt_hip_ctx {
     unsigned long long* counters = nullptr;
     hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // the trace kernels that run beside the scatter kernel
     hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evIn = nullptr, evOut = nullptr; // order the pipeline against a caller's stream
     void* wfBuffer = nullptr; // wavefront state + queues of one pass
     size_t wfBytes = 0;
     uint32_t wfGroups = 0;
@@ -971,6 +972,8 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
     for (int k = 0; k < 3; k++) {
         HIP_TRY(hipStreamCreate(&c->aux[k]));
         HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
@@ -1010,6 +1013,8 @@ void prt_hip_destroy(prt_hip_ctx* c)
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
     }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evIn) (void)hipEventDestroy(c->evIn);
+    if (c->evOut) (void)hipEventDestroy(c->evOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1263,7 +1268,16 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     if (p->samples == 0 || p->tileSize == 0 || p->nranks == 0 || p->rank >= p->nranks) return fail(PRT_HIP_EINVAL, "bad render params");
     if (W > 65535 || H > 65535 || p->samples / 8 > 255 || p->maxDepth > 255) return fail(PRT_HIP_EINVAL, "image, sample count or depth too large");
     HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // The pipeline always runs on the context's own streams (the main one and the three that carry the concurrent trace
+    // kernels; a foreign stream can share a hardware queue with one of those and serialise them -- 8 % on C3).  A caller's
+    // stream is ordered around it with two events: work queued on it before this call is finished before the first kernel
+    // starts, and whatever the caller queues next waits for the last one.
+    hipStream_t s = c->stream;
+    hipStream_t caller = (stream && (hipStream_t)stream != c->stream) ? (hipStream_t)stream : nullptr;
+    if (caller) {
+        HIP_TRY(hipEventRecord(c->evIn, caller));
+        HIP_TRY(hipStreamWaitEvent(s, c->evIn, 0));
+    }
     if (!d_rgb) {
         if (c->fbPixels != (size_t)W * H) {
             if (c->fb) (void)hipFree(c->fb);
@@ -1335,6 +1349,10 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("wavefront launch: ") + hipGetErrorString(le));
     HIP_TRY(hipEventRecord(ev1, s));
+    if (caller) {
+        HIP_TRY(hipEventRecord(c->evOut, s));
+        HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
+    }
     c->timed = true;
     return PRT_HIP_OK;
 }
