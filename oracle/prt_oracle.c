@@ -1085,6 +1085,76 @@ static uint32_t bvh_occluded_packet(const orc_scene* s, const orc_bvh* b, uint32
     return occludeMask;
 }
 
+/* ------------------------------------------------------------------ accounting of the any-hit queries
+ * Test infrastructure for the GPU path's event counters; RESULTS ARE NEVER TAKEN FROM HERE.  An occlusion query asks
+ * whether any triangle below boxes the ray passes is accepted; with maxT constant every box and triangle test depends
+ * on (ray, box or triangle) alone, so the answer does not depend on the visiting order.  prt_amd visits the child whose
+ * box the ray enters first (ties: child 0) instead of the reference's fixed order (bvh.cpp:617-620).  With
+ * orc_set_anyhit_accounting(1) nBox/nTri/nTap of occlusion queries count THAT visit, ray by ray (1 per root test, 2 per
+ * internal node, every triangle tested up to the first accepted one), and the wrappers below abort() if its answer
+ * ever differs from the reference traversal's -- the order-independence is checked on every ray the oracle traces. */
+static int g_anyhit_accounting = 0;
+void orc_set_anyhit_accounting(int mode) { g_anyhit_accounting = mode; }
+
+static float any_hit_key(const orc_node* n, const float org[3], const float invDir[3]) /* prt_device.h slab_entry_select */
+{
+    float a, c, m, v;
+    a = (n->lower[0] - org[0]) * invDir[0]; c = (n->upper[0] - org[0]) * invDir[0]; m = (a < c) ? a : c;
+    a = (n->lower[1] - org[1]) * invDir[1]; c = (n->upper[1] - org[1]) * invDir[1]; v = (a < c) ? a : c; m = (v > m) ? v : m;
+    a = (n->lower[2] - org[2]) * invDir[2]; c = (n->upper[2] - org[2]) * invDir[2]; v = (a < c) ? a : c; m = (v > m) ? v : m;
+    return m;
+}
+
+static int any_hit_box(const orc_node* n, const float org[3], const float invDir[3], float maxT, int soa)
+{
+    return soa ? orc_bbox_intersect_soa(n->lower, n->upper, org, invDir, maxT) : orc_bbox_intersect_bool(n->lower, n->upper, org, invDir, maxT);
+}
+
+static int count_any_hit(const orc_scene* s, const orc_bvh* b, const float org[3], const float dir[3], const float invDir[3],
+                         int swapXZ, int swapYZ, float maxT, int soa, orc_stats* st)
+{
+    const orc_node* nodes[STACK_SIZE];
+    int32_t sp = 0;
+    const orc_mesh* m = b->mesh;
+    st->nBox++;
+    if (!any_hit_box(&b->nodes[0], org, invDir, maxT, soa)) return 0;
+    const orc_node* node = &b->nodes[0];
+    for (;;) {
+        if (node->primCount == INTERNAL_NODE) {
+            const orc_node* c0 = node + 1;
+            const orc_node* c1 = &b->nodes[node->primOrSecondNodeIndex];
+            st->nBox += 2;
+            int h0 = any_hit_box(c0, org, invDir, maxT, soa), h1 = any_hit_box(c1, org, invDir, maxT, soa);
+            if (h0 && h1) {
+                int near0 = any_hit_key(c0, org, invDir) <= any_hit_key(c1, org, invDir);
+                if (sp >= STACK_SIZE) abort();
+                nodes[sp++] = near0 ? c1 : c0;
+                node = near0 ? c0 : c1;
+                continue;
+            }
+            if (h0) { node = c0; continue; }
+            if (h1) { node = c1; continue; }
+        } else {
+            const trivec_t* tv = &b->triVectors[node->triVectorIndex];
+            const uint32_t* primIndices = &b->primRemapping[node->primOrSecondNodeIndex];
+            for (uint32_t i = 0; i < node->primCount; i++) {
+                float p0[3], p1[3], p2[3], ijk[3];
+                tri_fetch(tv, (int)i, p0, p1, p2);
+                st->nTri++;
+                float t = orc_intersect_triangle(org, dir, swapXZ, swapYZ, p0, p1, p2, ijk);
+                if (!(t >= kTriEpsilon && t < maxT)) continue;
+                if (tv->alphaTest[i]) {
+                    const orc_material* mat = &m->materials[m->primMaterial[primIndices[i]]];
+                    if (!tex_test_alpha(&s->textures[mat->diffuseMap], tri_uv(tv, (int)i, ijk), soa, st)) continue;
+                }
+                return 1;
+            }
+        }
+        if (sp == 0) return 0;
+        node = nodes[--sp];
+    }
+}
+
 static void make_ray1(ray1_t* r, const float org[3], const float dir[3])
 {
     memcpy(r->org, org, 12);
@@ -1132,9 +1202,17 @@ int orc_occluded_single(const orc_scene* s, const float org[3], const float dir[
 {
     ray1_t ray;
     make_ray1(&ray, org, dir);
-    for (uint32_t i = 0; i < s->bvhCount; i++)
-        if (bvh_occluded_single(s, s->bvh[i], &ray, maxT, st)) return 1;
-    return 0;
+    const int recount = g_anyhit_accounting && st;
+    int counted = 0;
+    if (recount) {
+        for (uint32_t i = 0; i < s->bvhCount && !counted; i++)
+            counted = count_any_hit(s, s->bvh[i], ray.org, ray.dir, ray.invDir, ray.swapXZ, ray.swapYZ, maxT, 0, st);
+        st = NULL; /* the reference traversal below gives the answer and counts nothing */
+    }
+    int res = 0;
+    for (uint32_t i = 0; i < s->bvhCount && !res; i++) res = bvh_occluded_single(s, s->bvh[i], &ray, maxT, st);
+    if (recount && res != counted) abort(); /* the visiting order changed an any-hit answer: impossible */
+    return res;
 }
 
 uint32_t orc_occluded_packet(const orc_scene* s, uint32_t activeMask, const float org[8][3], const float dir[8][3],
@@ -1142,12 +1220,25 @@ uint32_t orc_occluded_packet(const orc_scene* s, uint32_t activeMask, const floa
 {
     ray8_t pk;
     make_ray8(&pk, org, dir, NULL, maxT);
+    const int recount = g_anyhit_accounting && st;
+    uint32_t counted = (~activeMask) & 0xff;
+    if (recount) {
+        for (int l = 0; l < LANES; l++) {
+            if (!(activeMask & (1u << l))) continue;
+            int c = 0;
+            for (uint32_t i = 0; i < s->bvhCount && !c; i++)
+                c = count_any_hit(s, s->bvh[i], pk.org[l], pk.dir[l], pk.invDir[l], pk.swapXZ[l], pk.swapYZ[l], pk.maxT[l], 1, st);
+            if (c) counted |= 1u << l;
+        }
+        st = NULL;
+    }
     uint32_t occludeMask = (~activeMask) & 0xff;
     for (uint32_t i = 0; i < s->bvhCount; i++) {
         uint32_t res = bvh_occluded_packet(s, s->bvh[i], (~occludeMask) & 0xff, &pk, st);
         occludeMask |= res;
-        if (occludeMask == 0xff) return occludeMask;
+        if (occludeMask == 0xff) break;
     }
+    if (recount && occludeMask != counted) abort();
     return occludeMask;
 }
 

@@ -162,6 +162,10 @@ void orc_x_sample_bump(const float normal[3], int32_t w, int32_t h, int32_t comp
 void orc_libm_sincos(uint32_t n, const float* theta, float* s, float* c);
 void orc_libm_powf22(uint32_t n, const float* x, float* y);
 
+/* counters of occlusion queries: 0 = what the reference's traversal does (default), 1 = what prt_amd's near-first
+ * per-ray visit does (see prt_oracle.c, "accounting of the any-hit queries").  Never changes a result. */
+void orc_set_anyhit_accounting(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,10 +15,24 @@
 #define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (reference + entry distance: 8 B each)
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
-#ifndef PRT_LEAF_BREAK
-#define PRT_LEAF_BREAK 28 // lanes waiting on a leaf that end the node phase early
+#ifndef PRT_RULE
+#define PRT_RULE 0
 #endif
-
+#ifndef PRT_STAY
+#define PRT_STAY 24
+#endif
+#ifndef PRT_NODE_W
+#define PRT_NODE_W 1
+#endif
+#ifndef PRT_LEAF_W
+#define PRT_LEAF_W 1
+#endif
+#ifndef PRT_TRI2
+#define PRT_TRI2 1
+#endif
+#ifndef PRT_IDLE_BREAK
+#define PRT_IDLE_BREAK 8 // lanes without a node or triangle to step on that send the wave back to the refill point
+#endif
 // ---------------------------------------------------------------------------- device scene
 // wnodes: 4 x float4 (64 B) per INTERNAL node, (lo, hi) pairs per axis so that the slab arithmetic runs on packed
 //         f32 pairs: {lo0.x hi0.x lo0.y hi0.y} {lo0.z hi0.z lo1.z hi1.z} {lo1.x hi1.x lo1.y hi1.y} {ref0 ref1 splitAxis 0}
@@ -213,6 +227,18 @@ __device__ __forceinline__ float box_soa_entry(const Box& b, const DevRay& r)
 }
 __device__ __forceinline__ bool box_soa(const Box& b, const DevRay& r, float maxT) { return box_soa_entry(b, r) < maxT; }
 
+// Ordering key of the any-hit traversal for rays off the NaN-free path: the largest slab entry, written with selects so
+// that the test suite's CPU accounting of this visit evaluates the same expression.  For NaN-free rays it
+// equals the max_t0 of the packed slab arithmetic.
+__device__ __forceinline__ float slab_entry_select(const Box& b, const DevRay& r)
+{
+    float a, c, m, v;
+    a = (b.lo.x - r.org.x) * r.inv.x; c = (b.hi.x - r.org.x) * r.inv.x; m = (a < c) ? a : c;
+    a = (b.lo.y - r.org.y) * r.inv.y; c = (b.hi.y - r.org.y) * r.inv.y; v = (a < c) ? a : c; m = (v > m) ? v : m;
+    a = (b.lo.z - r.org.z) * r.inv.z; c = (b.hi.z - r.org.z) * r.inv.z; v = (a < c) ? a : c; m = (v > m) ? v : m;
+    return m;
+}
+
 // ---------------------------------------------------------------------------- triangle
 // triangle.cpp:90-166, one lane.  Returns t, or -1 (kNoIntersection).
 __device__ __forceinline__ float tri_intersect(const DevRay& r, Vec3 p0, Vec3 p1, Vec3 p2, float& bi, float& bj, float& bk)
@@ -335,7 +361,6 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, V
 //   internal: index of the child's own wide record (< 2^30)
 //   leaf:     PRT_REF_LEAF | firstTriangle << 4 | primCount      (primCount 1..8, firstTriangle < 2^27)
 #define PRT_REF_LEAF 0x80000000u
-#define PRT_REF_DEAD 0xffffffffu // counting builds only: a child that failed its box test, kept so that it is counted when popped
 
 // Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper
 // ones in a per-thread global spill area.  `t` (the box entry distance) is only stored by the packet traversal.
@@ -396,32 +421,26 @@ __device__ __forceinline__ Box root_box(const DevScene& sc, uint32_t m)
     return Box{mk3(sc.rootBox[m][0], sc.rootBox[m][1], sc.rootBox[m][2]), mk3(sc.rootBox[m][3], sc.rootBox[m][4], sc.rootBox[m][5])};
 }
 
-// bvh.cpp:302-368 (kNearest / kOcclude) and :370-427 for one lane.  Returns true when occluded (OCCLUDE only).
+// One triangle of a leaf against one ray (the loop bodies of bvh.cpp:302-368 and :370-427 for one lane): true when the
+// candidate is accepted -- t in [kTriEpsilon, limit) and the alpha test, if the triangle has one, passed.  Nearest-hit
+// callers pass limit = hit.t and get hit updated; occlusion callers pass limit = maxT.
 template <bool OCCLUDE, bool PACKET, bool COUNT>
-__device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t ref, uint32_t meshId, const DevRay& r, float maxT, DevHit& hit,
-                                               Traffic& tr)
+__device__ __forceinline__ bool tri_candidate(const DevScene& sc, const float4* tp, uint32_t meshId, const DevRay& r, float limit, DevHit& hit,
+                                              Traffic& tr)
 {
-    const uint32_t primCount = ref & 15u, triStart = (ref >> 4) & 0x7ffffffu;
-    if (COUNT) tr.nTri += primCount;
-    // single: candidates need t < maxT with maxT = hit.t at leaf entry, nearest by strict <  (bvh.cpp:323,344)
-    // packet: t < hit.t, updated as the loop goes (bvh.cpp:392) -- the same running minimum
-    float best = maxT;
-    const float4* tp = sc.tris + 3 * (size_t)triStart;
-    for (uint32_t i = 0; i < primCount; i++, tp += 3) {
-        float4 a = tp[0], b = tp[1], c = tp[2];
-        float bi, bj, bk;
-        float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
-        if (!(t >= 0.0001f && t < best)) continue;
-        uint32_t alphaRef = asu(b.w);
-        if (alphaRef) {
-            const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
-            float4 u0 = ap[0], u1 = ap[1];
-            // i*uv0 + j*uv1 + k*uv2 (bvh.cpp:336, 407)
-            Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y};
-            if (!tex_test_alpha<COUNT>(sc, asu(u1.z), uv, PACKET, tr)) continue;
-        }
-        if (OCCLUDE) return true;
-        best = t;
+    float4 a = tp[0], b = tp[1], c = tp[2];
+    float bi, bj, bk;
+    float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
+    if (!(t >= 0.0001f && t < limit)) return false;
+    uint32_t alphaRef = asu(b.w);
+    if (alphaRef) {
+        const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
+        float4 u0 = ap[0], u1 = ap[1];
+        // i*uv0 + j*uv1 + k*uv2 (bvh.cpp:336, 407)
+        Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y};
+        if (!tex_test_alpha<COUNT>(sc, asu(u1.z), uv, PACKET, tr)) return false;
+    }
+    if (!OCCLUDE) {
         hit.t = t;
         hit.i = bi;
         hit.j = bj;
@@ -429,7 +448,7 @@ __device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t ref,
         hit.primId = asu(a.w);
         hit.meshId = meshId;
     }
-    return false;
+    return true;
 }
 
 // ---------------------------------------------------------------------------- the four traversals as ONE stepper
@@ -447,9 +466,11 @@ __device__ __forceinline__ bool leaf_intersect(const DevScene& sc, uint32_t ref,
 //     stack and the hit.t part of the test is redone at the pop -- the same decision.
 //  1: root bool test (vecmath.h:1449); both children tested per internal node against the current hit.t
 //     (vecmath.h:1402), near child first (t0 < t1, ties -> second child first), popped nodes NOT re-tested (bvh.cpp:474).
-//  2/3: any-hit, fixed order (first child popped first); maxT is constant, so testing a child at its parent equals
-//     testing it at its pop.  Counting builds keep failed children on the stack (PRT_REF_DEAD) so that a box test is
-//     counted exactly when the reference performs it (children still stacked when the ray is found occluded never are).
+//  2/3: any-hit.  maxT is constant, so every box and triangle test is a function of (ray, box or triangle) alone and the
+//     answer -- is ANY triangle below boxes the ray passes accepted -- does not depend on the order of the visit.  The
+//     reference pops the first child first (bvh.cpp:617-620); here the child whose box the ray enters first goes first
+//     (ties: child 0), which finds an occluder after about half the nodes and triangles on the C3 scene.  The counters
+//     count the tests this traversal performs (2 per internal node visited, 1 per root, every triangle tested).
 #define PRT_MODE_PACKET 0
 #define PRT_MODE_SINGLE 1
 #define PRT_MODE_OCC_PACKET 2
@@ -499,12 +520,8 @@ __device__ __forceinline__ uint32_t tracer_pop(Tracer& T, const Stack& st, Traff
         if (T.sp == 0) return PRT_REF_NONE;
         return st.get(--T.sp);
     } else {
-        while (T.sp > 0) {
-            uint32_t r = st.get(--T.sp);
-            if (COUNT) tr.nBox++;
-            if (r != PRT_REF_DEAD) return r;
-        }
-        return PRT_REF_NONE;
+        if (T.sp == 0) return PRT_REF_NONE;
+        return st.get(--T.sp);
     }
 }
 
@@ -527,6 +544,22 @@ __device__ __forceinline__ bool tracer_next_bvh(const DevScene& sc, Tracer& T, T
             T.sp = 0;
             return true;
         }
+    }
+}
+
+// Any-hit modes: both children passed -> the nearer first, the other stacked.
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void tracer_any_hit_order(Tracer& T, const Stack& st, Traffic& tr, const WideNode& w, bool h0, bool h1, bool near0)
+{
+    if (h0 && h1) {
+        st.put(T.sp++, near0 ? w.ref1 : w.ref0);
+        T.ref = near0 ? w.ref0 : w.ref1;
+    } else if (h0) {
+        T.ref = w.ref0;
+    } else if (h1) {
+        T.ref = w.ref1;
+    } else {
+        T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
     }
 }
 
@@ -575,14 +608,8 @@ __device__ __forceinline__ void tracer_decide(const DevScene& sc, Tracer& T, con
             h0 = __builtin_fminf(e.mn0, w1) > __builtin_fmaxf(e.mx0, w0);
             h1 = __builtin_fminf(e.mn1, w1) > __builtin_fmaxf(e.mx1, w0);
         }
-        if (COUNT) {
-            st.put(T.sp++, h1 ? w.ref1 : PRT_REF_DEAD);
-            tr.nBox++;
-        } else if (h1) {
-            st.put(T.sp++, w.ref1);
-        }
-        if (h0) T.ref = w.ref0;
-        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+        if (COUNT) tr.nBox += 2;
+        tracer_any_hit_order<MODE, COUNT>(T, st, tr, w, h0, h1, e.mx0 <= e.mx1);
     }
 }
 
@@ -640,26 +667,23 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
     } else {
         bool h0 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(wb0, T.r, T.maxT) : box_bool(wb0, T.r, T.maxT);
         bool h1 = (MODE == PRT_MODE_OCC_PACKET) ? box_soa(wb1, T.r, T.maxT) : box_bool(wb1, T.r, T.maxT);
-        if (COUNT) {
-            st.put(T.sp++, h1 ? w.ref1 : PRT_REF_DEAD);
-            tr.nBox++; // child 0 is popped next
-        } else if (h1) {
-            st.put(T.sp++, w.ref1);
-        }
-        if (h0) T.ref = w.ref0;
-        else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+        if (COUNT) tr.nBox += 2;
+        tracer_any_hit_order<MODE, COUNT>(T, st, tr, w, h0, h1, slab_entry_select(wb0, T.r) <= slab_entry_select(wb1, T.r));
     }
 }
 
+// One triangle of the leaf the lane stands on.  A leaf reference is its own cursor: (first triangle, triangles left), so
+// the step leaves the lane on the rest of the leaf or pops.  Stepping triangle by triangle (not leaf by leaf) lets the
+// wave loop regroup lanes after every triangle: a leaf of 8 no longer holds up lanes whose leaf had 1.
 template <int MODE, bool COUNT>
-__device__ __forceinline__ void tracer_leaf(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr)
+__device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr)
 {
-    if (MODE == PRT_MODE_PACKET) {
-        leaf_intersect<false, true, COUNT>(sc, T.ref, T.m, T.r, T.hit.t, T.hit, tr);
-    } else if (MODE == PRT_MODE_SINGLE) {
-        leaf_intersect<false, false, COUNT>(sc, T.ref, T.m, T.r, T.hit.t, T.hit, tr);
-    } else {
-        if (leaf_intersect<true, MODE == PRT_MODE_OCC_PACKET, COUNT>(sc, T.ref, T.m, T.r, T.maxT, T.hit, tr)) {
+    constexpr bool OCC = (MODE == PRT_MODE_OCC_PACKET || MODE == PRT_MODE_OCC_SINGLE);
+    constexpr bool PACKET = (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET);
+    const uint32_t left = T.ref & 15u, tri = (T.ref >> 4) & 0x7ffffffu;
+    if (left != 0u) {
+        if (COUNT) tr.nTri++;
+        if (tri_candidate<OCC, PACKET, COUNT>(sc, sc.tris + 3 * (size_t)tri, T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
             T.occ = true;
             T.ref = PRT_REF_NONE;
             T.sp = 0;
@@ -667,7 +691,23 @@ __device__ __forceinline__ void tracer_leaf(const DevScene& sc, Tracer& T, const
             return;
         }
     }
-    T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+#if PRT_TRI2
+    if (left > 1u) {
+        if (COUNT) tr.nTri++;
+        if (tri_candidate<OCC, PACKET, COUNT>(sc, sc.tris + 3 * (size_t)(tri + 1u), T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
+            T.occ = true;
+            T.ref = PRT_REF_NONE;
+            T.sp = 0;
+            T.m = sc.bvhCount;
+            return;
+        }
+    }
+    if (left > 2u) T.ref += 30u;
+    else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+#else
+    if (left > 1u) T.ref += 15u; // first triangle + 1 (bit 4), triangles left - 1
+    else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
+#endif
 }
 
 __device__ __forceinline__ bool ref_is_internal(uint32_t ref) { return !(ref & PRT_REF_LEAF); }
@@ -742,17 +782,29 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                 active = false;
             }
         }
-        // Node phase: lanes on internal nodes step together.  It ends when no lane is on an internal node -- or, sooner, when
-        // enough lanes are waiting on a leaf (PRT_LEAF_BREAK): a few long descents (every freshly fetched ray starts at the
-        // root) must not keep the rest of the wave idle.
+        // Step phase: a step is one internal node or one triangle.  Each round the larger of the two groups of lanes steps
+        // (the other waits: SIMD lanes that cannot share an instruction stream), until PRT_IDLE_BREAK lanes have nothing
+        // to step on -- their ray is finished or moves to the next BVH -- and the wave goes back to the top to serve them.
+        bool lastNode = true;
         for (;;) {
             const bool onNode = active && ref_is_internal(T.ref);
-            const unsigned long long nodeMask = __ballot(onNode);
-            if (nodeMask == 0ull) break;
-            if ((uint32_t)__popcll(__ballot(active && ref_is_leaf(T.ref))) >= PRT_LEAF_BREAK) break;
-            if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+            const bool onLeaf = active && ref_is_leaf(T.ref);
+            const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
+            if (nNode + nLeaf == 0u) break;
+#if PRT_RULE == 1
+            const bool keep = (lastNode ? nNode : nLeaf) >= PRT_STAY;
+            const bool doNode = keep ? lastNode : (nNode >= nLeaf);
+            lastNode = doNode;
+#else
+            const bool doNode = nNode * PRT_NODE_W >= nLeaf * PRT_LEAF_W;
+#endif
+            if (doNode) {
+                if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+            } else {
+                if (onLeaf) tracer_tri<MODE, COUNT>(sc, T, st, tr);
+            }
+            if ((uint32_t)__popcll(__ballot(active && T.ref == PRT_REF_NONE)) >= PRT_IDLE_BREAK) break;
         }
-        if (active && ref_is_leaf(T.ref)) tracer_leaf<MODE, COUNT>(sc, T, st, tr);
     }
 }
 

@@ -131,6 +131,8 @@ def oracle():
                              C.POINTER(OrcStats)]
     L.orc_max_threads.restype = C.c_int
     L.orc_render_rect.argtypes = [vp, C.POINTER(OrcCamera)] + [C.c_uint32] * 7 + [C.c_float, C.c_int, vp, C.POINTER(OrcStats)]
+    L.orc_set_anyhit_accounting.argtypes = [C.c_int]
+    L.orc_set_anyhit_accounting.restype = None
     L.orc_libm_sincos.argtypes = [C.c_uint32, vp, vp, vp]
     L.orc_libm_powf22.argtypes = [C.c_uint32, vp, vp]
     _oracle = L

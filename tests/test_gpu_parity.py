@@ -27,6 +27,15 @@ def assert_bits_equal(a, b, what=""):
     assert len(bad[0]) == 0, f"{what}: {len(bad[0])} of {a.size} differ, first at {tuple(int(x[0]) for x in bad)}"
 
 
+@pytest.fixture(scope="module", autouse=True)
+def gpu_event_accounting():
+    """The oracle's nBox/nTri/nTap for occlusion queries follow the GPU's near-first visit in this module (the images
+    and ray counts are the reference traversal's either way; the oracle aborts if the two visits ever disagree)."""
+    T.oracle().orc_set_anyhit_accounting(1)
+    yield
+    T.oracle().orc_set_anyhit_accounting(0)
+
+
 @pytest.fixture(scope="module")
 def tracer():
     prt_amd.build()

@@ -152,3 +152,25 @@ def test_radiance_matches_reference():
     assert st2["raysTraced"] == int(z["cornell_only_rays"][0]) == 1126145
     m = rgb2.reshape(-1, 3).astype(np.float64).mean(0)
     assert np.allclose(m, [0.198639526, 0.130990393, 0.039316328], rtol=0, atol=5e-9)
+
+
+def test_any_hit_answers_do_not_depend_on_the_visiting_order(oracle_lib):
+    """The GPU path visits the nearer child first in occlusion queries (the reference: child 0 first).  With the GPU's
+    accounting on, the oracle walks every occlusion ray both ways and abort()s on a differing answer; the image must be
+    the same bits and only the occlusion share of nBox/nTri may change."""
+    import prt_amd
+    scene, camera, exposure = prt_amd.setup_atrium_standin(96, 54, tris=20000)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    s = T.OracleScene(desc)
+    try:
+        oracle_lib.orc_set_anyhit_accounting(0)
+        ref, st0 = s.render(8, max_depth=8)
+        oracle_lib.orc_set_anyhit_accounting(1)
+        img, st1 = s.render(8, max_depth=8)
+    finally:
+        oracle_lib.orc_set_anyhit_accounting(0)
+    assert_bits_equal(img, ref, "image under the two accountings")
+    assert st0["occludedTraced"] > 1000
+    for k in ("raysTraced", "occludedTraced", "nHit", "nPx", "rngDraws"):
+        assert st0[k] == st1[k], k
+    assert st1["nBox"] < st0["nBox"] and st1["nTri"] < st0["nTri"]

@@ -1,0 +1,22 @@
+"""Time the C3 frame with every library in prt_amd/lib/var/ (one child process each).  Diagnostic only."""
+import os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1:
+    sys.path.insert(0, root)
+    import prt_amd
+    prt_amd.LIB_PATH = sys.argv[1]
+    W, H, spp, depth = 1920, 1080, 64, 8
+    scene, camera, exposure = prt_amd.setup_atrium_standin(W, H, tris=262000, seed=1)
+    tr = prt_amd.PathTracer(device=0, max_depth=depth, seed=12345)
+    tr.upload_scene(scene); tr.set_camera(camera)
+    ms = []
+    for i in range(3):
+        tr.render_async(0, 0, W - 1, H - 1, spp, exposure=exposure)
+        st = tr.stats()
+        ms.append(st["kernelMs"])
+    print(f"{os.path.basename(sys.argv[1])}: {min(ms):.1f} ms  ({st['raysTraced'] / min(ms) / 1e3:.0f} Mray/s)", flush=True)
+    tr.close()
+else:
+    var = os.path.join(root, "prt_amd", "lib", "var")
+    for f in sorted(os.listdir(var)):
+        subprocess.call([sys.executable, os.path.abspath(__file__), os.path.join(var, f)])
