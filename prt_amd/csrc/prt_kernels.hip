@@ -125,6 +125,8 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
+#define PRT_PARTS 2        // independent pipelines a pass is dealt to
+#define PRT_WORK_WORDS 128 // queue counters of one pipeline (4 + Q_COUNT * PRT_QSHARDS used)
 #define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
 #define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
 #define SLOT_HAS_SHADOW 1u
@@ -152,7 +154,8 @@ struct WfArgs {
     uint32_t tilesXImage;
     uint32_t rtx0, rty0, rtnx, rtny;
     uint32_t fullWidth, firstOwned;
-    uint32_t workBase;   // first work item (tile-major pixel index) of this pass
+    uint32_t workBase;   // first work item (tile-major pixel index) of this pass, a multiple of the tile area
+    uint32_t partIndex, partCount; // the pass is dealt to partCount independent pipelines tile by tile; this is pipeline partIndex
     uint32_t groupCount; // pixel groups in this pass
     float* rgb;
     unsigned long long* counters; // rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
@@ -583,8 +586,8 @@ __global__ void init_groups_kernel(WfArgs A)
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= A.groupCount) return;
     const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
-    uint32_t w = A.workBase + g;
-    uint32_t tq = w / tile2, pix = w - tq * tile2;
+    const uint32_t tl = g / tile2, pix = g - tl * tile2; // tl-th tile of this pipeline
+    const uint32_t tq = A.workBase / tile2 + tl * A.partCount + A.partIndex;
     uint32_t gt;
     bool ok = true;
     if (A.fullWidth) {
@@ -898,8 +901,12 @@ struct prt_hip_ctx {
     size_t fbPixels = 0;
     uint32_t* work = nullptr; // Q_COUNT queue counters
     unsigned long long* counters = nullptr;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // the trace kernels that run beside the scatter kernel
-    hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
+    // Two independent pipelines (halves of a pass, dealt tile by tile) run side by side, each on a main stream (shade,
+    // scatter trace) and a side stream (the other three trace kernels): stream, aux[0] | aux[1], aux[2].  Four streams =
+    // the four hardware queues a HIP process gets by default.
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evFork[PRT_PARTS] = {}, evJoin[PRT_PARTS] = {};
+    hipEvent_t evStart = nullptr, evDone = nullptr; // pipeline 1 against the main stream, per pass
     hipEvent_t evIn = nullptr, evOut = nullptr; // order the pipeline against a caller's stream
     void* wfBuffer = nullptr; // wavefront state + queues of one pass
     size_t wfBytes = 0;
@@ -922,27 +929,38 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
     return PRT_HIP_OK;
 }
 
-// One iteration.  The four trace kernels of an iteration are independent of each other: three run on auxiliary
-// streams beside the scatter kernel so that the tail of one persistent grid is filled by the next (each has its own
-// stack-spill area); the next shade kernel waits for all four.
+// One pipeline of a pass: its groups, queues and streams.
+struct PartRun {
+    WfArgs A;
+    uint32_t shadeBlocks = 0;
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int index = 0;
+};
+
+// One iteration of one pipeline.  The four trace kernels of an iteration are independent of each other: the scatter kernel
+// (the longest) runs on the main stream, the other three on the side stream beside it, so that the tail of one persistent
+// grid is filled by the next (each kernel has its own stack-spill area); the next shade kernel waits for all four.  The
+// other pipeline's kernels fill what this one leaves idle -- above all the time its shade kernel would hold the GPU alone.
 template <bool COUNT>
-static void wf_iteration(prt_hip_ctx* c, const WfArgs& A, uint32_t shadeBlocks, uint32_t traceBlocks, hipStream_t s)
+static void wf_iteration(const PartRun& P, uint32_t traceBlocks)
 {
-    (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), s); // claim cursors + shard counts
-    hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(shadeBlocks), dim3(PRT_BLOCK), 0, s, A);
-    (void)hipEventRecord(c->evFork, s);
+    const WfArgs& A = P.A;
+    (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), P.main); // claim cursors + shard counts
+    hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
+    (void)hipEventRecord(P.fork, P.main);
     const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
     WfArgs B = A;
-    for (int k = 0; k < 3; k++) {
-        (void)hipStreamWaitEvent(c->aux[k], c->evFork, 0);
-        B.spill = A.spill + (size_t)(k + 1) * spillWords;
-        if (k == 0) hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
-        else if (k == 1) hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
-        else hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, c->aux[k], B);
-        (void)hipEventRecord(c->evJoin[k], c->aux[k]);
-    }
-    hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, s, A);
-    for (int k = 0; k < 3; k++) (void)hipStreamWaitEvent(s, c->evJoin[k], 0);
+    (void)hipStreamWaitEvent(P.side, P.fork, 0);
+    B.spill = A.spill + 1 * spillWords;
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
+    B.spill = A.spill + 2 * spillWords;
+    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
+    B.spill = A.spill + 3 * spillWords;
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
+    (void)hipEventRecord(P.join, P.side);
+    hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.main, A);
+    (void)hipStreamWaitEvent(P.main, P.join, 0);
 }
 
 extern "C" {
@@ -971,15 +989,17 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
-    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
-    for (int k = 0; k < 3; k++) {
-        HIP_TRY(hipStreamCreate(&c->aux[k]));
+    for (int k = 0; k < PRT_PARTS; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->evFork[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
     }
-    HIP_TRY(hipMalloc(&c->work, 1024));
-    HIP_TRY(hipMemset(c->work, 0, 1024));
+    HIP_TRY(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evDone, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
+    HIP_TRY(hipMalloc(&c->work, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     *out = c;
@@ -1008,11 +1028,14 @@ void prt_hip_destroy(prt_hip_ctx* c)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3; k++)
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    for (int k = 0; k < PRT_PARTS; k++) {
+        if (c->evFork[k]) (void)hipEventDestroy(c->evFork[k]);
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
     }
-    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evDone) (void)hipEventDestroy(c->evDone);
     if (c->evIn) (void)hipEventDestroy(c->evIn);
     if (c->evOut) (void)hipEventDestroy(c->evOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1205,8 +1228,8 @@ static int ensure_launch_resources(prt_hip_ctx* c, uint32_t blocks)
     if (threads > c->spillThreads) {
         if (c->spill) (void)hipFree(c->spill);
         c->spill = nullptr;
-        // four areas: one per concurrently running trace kernel
-        HIP_TRY(hipMalloc(&c->spill, 4 * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
+        // one area per concurrently running trace kernel: four per pipeline
+        HIP_TRY(hipMalloc(&c->spill, 4 * PRT_PARTS * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
         c->spillThreads = threads;
     }
     return PRT_HIP_OK;
@@ -1217,22 +1240,27 @@ static int persistent_blocks(prt_hip_ctx* c)
     if (c->blocksPerCU == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<Q_SCATTER, false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 2;
-        c->blocksPerCU = std::min(nb, 8);
+        // Up to eight trace kernels are in flight (two pipelines x four queues) and a CU holds 8 blocks of 256 threads: 4 per
+        // kernel and CU leaves room for the other pipeline's kernels (measured on C3: 1: 933 ms, 2: 627, 3: 594, 4: 588,
+        // 5: 599, 6: 608, 8: 631)
+        c->blocksPerCU = std::min(nb, 4);
     }
     return c->computeUnits * c->blocksPerCU;
 }
 
-// Carves the wavefront state of `groups` pixel groups out of one allocation.
-static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
+// Carves the wavefront state of the pipelines of a pass (groups[k] pixel groups each) out of one allocation.
+static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, WfArgs* A)
 {
-    const size_t slots = (size_t)groups * 8;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    auto entries = [](size_t slots) { return slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK; };
     size_t need = 0;
-    const size_t qEntries = slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK;
-    need += 3 * al(groups * sizeof(uint32_t)) + al(groups * sizeof(float4));
-    need += 5 * al(slots * sizeof(float4));                                                        // S0..S4
-    need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t)); // hits, occlusion
-    need += Q_COUNT * al(qEntries * sizeof(uint32_t));
+    for (int k = 0; k < parts; k++) {
+        const size_t g = groups[k], slots = g * 8;
+        need += 3 * al(g * sizeof(uint32_t)) + al(g * sizeof(float4));
+        need += 5 * al(slots * sizeof(float4));                                                        // S0..S4
+        need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t)); // hits, occlusion
+        need += Q_COUNT * al(entries(slots) * sizeof(uint32_t));
+    }
     if (need > c->wfBytes) {
         if (c->wfBuffer) (void)hipFree(c->wfBuffer);
         c->wfBuffer = nullptr;
@@ -1242,19 +1270,22 @@ static int wf_layout(prt_hip_ctx* c, uint32_t groups, WfArgs& A)
     }
     char* p = (char*)c->wfBuffer;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return r; };
-    A.gRng = (uint32_t*)take(groups * sizeof(uint32_t));
-    A.gInfo = (uint32_t*)take(groups * sizeof(uint32_t));
-    A.gPixel = (uint32_t*)take(groups * sizeof(uint32_t));
-    A.gColor = (float4*)take(groups * sizeof(float4));
-    A.S0 = (float4*)take(slots * sizeof(float4));
-    A.S1 = (float4*)take(slots * sizeof(float4));
-    A.S2 = (float4*)take(slots * sizeof(float4));
-    A.S3 = (float4*)take(slots * sizeof(float4));
-    A.S4 = (float4*)take(slots * sizeof(float4));
-    A.hitA = (float4*)take(slots * sizeof(float4));
-    A.hitB = (uint2*)take(slots * sizeof(uint2));
-    A.occl = (uint32_t*)take(slots * sizeof(uint32_t));
-    for (int q = 0; q < Q_COUNT; q++) A.qE[q] = (uint32_t*)take(qEntries * sizeof(uint32_t));
+    for (int k = 0; k < parts; k++) {
+        const size_t g = groups[k], slots = g * 8;
+        A[k].gRng = (uint32_t*)take(g * sizeof(uint32_t));
+        A[k].gInfo = (uint32_t*)take(g * sizeof(uint32_t));
+        A[k].gPixel = (uint32_t*)take(g * sizeof(uint32_t));
+        A[k].gColor = (float4*)take(g * sizeof(float4));
+        A[k].S0 = (float4*)take(slots * sizeof(float4));
+        A[k].S1 = (float4*)take(slots * sizeof(float4));
+        A[k].S2 = (float4*)take(slots * sizeof(float4));
+        A[k].S3 = (float4*)take(slots * sizeof(float4));
+        A[k].S4 = (float4*)take(slots * sizeof(float4));
+        A[k].hitA = (float4*)take(slots * sizeof(float4));
+        A[k].hitB = (uint2*)take(slots * sizeof(uint2));
+        A[k].occl = (uint32_t*)take(slots * sizeof(uint32_t));
+        for (int q = 0; q < Q_COUNT; q++) A[k].qE[q] = (uint32_t*)take(entries(slots) * sizeof(uint32_t));
+    }
     return PRT_HIP_OK;
 }
 
@@ -1318,11 +1349,39 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     const uint32_t traceBlocks = (uint32_t)persistent_blocks(c);
     int rc = ensure_launch_resources(c, traceBlocks);
     if (rc) return rc;
-    A.spill = c->spill;
     A.spillStride = c->spillThreads;
-    const uint32_t kMaxGroupsPerPass = 4u << 20; // 2^26 slot references fit the 26-bit owner field of a queued ray
-    const uint32_t passGroups = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(totalWork, 1), kMaxGroupsPerPass);
-    if ((rc = wf_layout(c, passGroups, A))) return rc;
+    // A pass holds at most 2^26 slot references (the 26-bit owner field of a queued ray) per pipeline and whole tiles.
+    const uint32_t tile2 = T * T;
+    if (tile2 > (1u << 20)) return fail(PRT_HIP_EINVAL, "tile too large");
+    const uint64_t totalTiles = totalWork / tile2;
+    const uint64_t kMaxGroupsPerPass = 4u << 20;
+    const uint64_t passTiles = std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(totalTiles, 1), kMaxGroupsPerPass / tile2));
+    // two pipelines as soon as each gets a few tiles; tiny launches keep one
+    const int parts = (std::min<uint64_t>(passTiles, totalTiles) >= 8) ? PRT_PARTS : 1;
+    PartRun P[PRT_PARTS];
+    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
+    {
+        uint32_t maxGroups[PRT_PARTS];
+        WfArgs L[PRT_PARTS];
+        for (int k = 0; k < parts; k++) maxGroups[k] = (uint32_t)(((passTiles - k + parts - 1) / parts) * tile2);
+        if ((rc = wf_layout(c, maxGroups, parts, L))) return rc;
+        for (int k = 0; k < parts; k++) {
+            P[k].A = A;
+            P[k].A.gRng = L[k].gRng; P[k].A.gInfo = L[k].gInfo; P[k].A.gPixel = L[k].gPixel; P[k].A.gColor = L[k].gColor;
+            P[k].A.S0 = L[k].S0; P[k].A.S1 = L[k].S1; P[k].A.S2 = L[k].S2; P[k].A.S3 = L[k].S3; P[k].A.S4 = L[k].S4;
+            P[k].A.hitA = L[k].hitA; P[k].A.hitB = L[k].hitB; P[k].A.occl = L[k].occl;
+            for (int q = 0; q < Q_COUNT; q++) P[k].A.qE[q] = L[k].qE[q];
+            P[k].A.qWork = c->work + (size_t)k * PRT_WORK_WORDS;
+            P[k].A.spill = c->spill + (size_t)k * 4 * spillWords;
+            P[k].A.partIndex = (uint32_t)k;
+            P[k].A.partCount = (uint32_t)parts;
+            P[k].main = (k == 0) ? s : c->aux[1];
+            P[k].side = (k == 0) ? c->aux[0] : c->aux[2];
+            P[k].fork = c->evFork[k];
+            P[k].join = c->evJoin[k];
+            P[k].index = k;
+        }
+    }
 
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
     if (c->eventsUsed == c->events.size()) {
@@ -1335,15 +1394,34 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     c->eventsUsed++;
     HIP_TRY(hipEventRecord(ev0, s));
     const uint32_t iterations = (p->samples / 8) * (1 + p->maxDepth) + 1;
-    for (uint64_t base = 0; base < totalWork; base += passGroups) {
-        A.workBase = (uint32_t)base;
-        A.groupCount = (uint32_t)std::min<uint64_t>(passGroups, totalWork - base);
-        hipLaunchKernelGGL(init_groups_kernel, dim3((A.groupCount + 255) / 256), dim3(256), 0, s, A);
-        const uint32_t shadeBlocks = (uint32_t)(((uint64_t)A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
-        A.shardCap = ((shadeBlocks + PRT_QSHARDS - 1) / PRT_QSHARDS) * PRT_BLOCK;
+    for (uint64_t baseTile = 0; baseTile < totalTiles; baseTile += passTiles) {
+        const uint64_t tilesNow = std::min<uint64_t>(passTiles, totalTiles - baseTile);
+        // pipeline 1 starts after everything queued on the main stream so far (the previous pass included)
+        if (parts > 1) {
+            HIP_TRY(hipEventRecord(c->evStart, s));
+            HIP_TRY(hipStreamWaitEvent(P[1].main, c->evStart, 0));
+        }
+        int live = 0;
+        for (int k = 0; k < parts; k++) {
+            const uint64_t tilesOfPart = (tilesNow > (uint64_t)k) ? (tilesNow - k + parts - 1) / parts : 0;
+            P[k].A.workBase = (uint32_t)(baseTile * tile2);
+            P[k].A.groupCount = (uint32_t)(tilesOfPart * tile2);
+            P[k].shadeBlocks = (uint32_t)(((uint64_t)P[k].A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
+            P[k].A.shardCap = ((P[k].shadeBlocks + PRT_QSHARDS - 1) / PRT_QSHARDS) * PRT_BLOCK;
+            if (P[k].A.groupCount == 0) continue;
+            live = k + 1;
+            hipLaunchKernelGGL(init_groups_kernel, dim3((P[k].A.groupCount + 255) / 256), dim3(256), 0, P[k].main, P[k].A);
+        }
         for (uint32_t it = 0; it < iterations; it++) {
-            if (p->countTraffic) wf_iteration<true>(c, A, shadeBlocks, traceBlocks, s);
-            else wf_iteration<false>(c, A, shadeBlocks, traceBlocks, s);
+            for (int k = 0; k < live; k++) {
+                if (P[k].A.groupCount == 0) continue;
+                if (p->countTraffic) wf_iteration<true>(P[k], traceBlocks);
+                else wf_iteration<false>(P[k], traceBlocks);
+            }
+        }
+        if (parts > 1) {
+            HIP_TRY(hipEventRecord(c->evDone, P[1].main));
+            HIP_TRY(hipStreamWaitEvent(s, c->evDone, 0));
         }
     }
     hipError_t le = hipGetLastError();
