@@ -125,7 +125,9 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
-#define PRT_PARTS 2        // independent pipelines a pass is dealt to
+#ifndef PRT_PARTS
+#define PRT_PARTS 2 // independent pipelines a pass is dealt to
+#endif
 #define PRT_WORK_WORDS 128 // queue counters of one pipeline (4 + Q_COUNT * PRT_QSHARDS used)
 #define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
 #define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
@@ -901,12 +903,13 @@ struct prt_hip_ctx {
     size_t fbPixels = 0;
     uint32_t* work = nullptr; // Q_COUNT queue counters
     unsigned long long* counters = nullptr;
-    // Two independent pipelines (halves of a pass, dealt tile by tile) run side by side, each on a main stream (shade,
-    // scatter trace) and a side stream (the other three trace kernels): stream, aux[0] | aux[1], aux[2].  Four streams =
-    // the four hardware queues a HIP process gets by default.
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    // PRT_PARTS independent pipelines (a pass dealt tile by tile) run side by side, each on a main stream (shade, scatter
+    // trace) and a side stream (the other three trace kernels): stream, aux[0] | aux[1], aux[2] | ...  Two pipelines = four
+    // streams = the four hardware queues a HIP process gets by default (measured on C3, whole frame / one rank's share of
+    // 8: 2 pipelines 588 / 102 ms; 3: 590-660 / 110-138; 4: 595-657 / 106-135 depending on GPU_MAX_HW_QUEUES).
+    hipStream_t aux[2 * PRT_PARTS - 1] = {};
     hipEvent_t evFork[PRT_PARTS] = {}, evJoin[PRT_PARTS] = {};
-    hipEvent_t evStart = nullptr, evDone = nullptr; // pipeline 1 against the main stream, per pass
+    hipEvent_t evStart = nullptr, evDone[PRT_PARTS] = {}; // pipelines 1.. against the main stream, per pass
     hipEvent_t evIn = nullptr, evOut = nullptr; // order the pipeline against a caller's stream
     void* wfBuffer = nullptr; // wavefront state + queues of one pass
     size_t wfBytes = 0;
@@ -994,10 +997,10 @@ int prt_hip_create(int device, prt_hip_ctx** out)
         HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evDone, hipEventDisableTiming));
+    for (int k = 0; k < PRT_PARTS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
-    for (int k = 0; k < 3; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
+    for (int k = 0; k < 2 * PRT_PARTS - 1; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
     HIP_TRY(hipMalloc(&c->work, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMemset(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
@@ -1028,14 +1031,15 @@ void prt_hip_destroy(prt_hip_ctx* c)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 2 * PRT_PARTS - 1; k++)
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
     for (int k = 0; k < PRT_PARTS; k++) {
         if (c->evFork[k]) (void)hipEventDestroy(c->evFork[k]);
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
     }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
-    if (c->evDone) (void)hipEventDestroy(c->evDone);
+    for (int k = 0; k < PRT_PARTS; k++)
+        if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]);
     if (c->evIn) (void)hipEventDestroy(c->evIn);
     if (c->evOut) (void)hipEventDestroy(c->evOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1357,7 +1361,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     const uint64_t kMaxGroupsPerPass = 4u << 20;
     const uint64_t passTiles = std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(totalTiles, 1), kMaxGroupsPerPass / tile2));
     // two pipelines as soon as each gets a few tiles; tiny launches keep one
-    const int parts = (std::min<uint64_t>(passTiles, totalTiles) >= 8) ? PRT_PARTS : 1;
+    const int parts = (std::min<uint64_t>(passTiles, totalTiles) >= 4 * PRT_PARTS) ? PRT_PARTS : 1;
     PartRun P[PRT_PARTS];
     const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
     {
@@ -1375,8 +1379,8 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
             P[k].A.spill = c->spill + (size_t)k * 4 * spillWords;
             P[k].A.partIndex = (uint32_t)k;
             P[k].A.partCount = (uint32_t)parts;
-            P[k].main = (k == 0) ? s : c->aux[1];
-            P[k].side = (k == 0) ? c->aux[0] : c->aux[2];
+            P[k].main = (k == 0) ? s : c->aux[2 * k - 1];
+            P[k].side = c->aux[2 * k];
             P[k].fork = c->evFork[k];
             P[k].join = c->evJoin[k];
             P[k].index = k;
@@ -1399,7 +1403,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         // pipeline 1 starts after everything queued on the main stream so far (the previous pass included)
         if (parts > 1) {
             HIP_TRY(hipEventRecord(c->evStart, s));
-            HIP_TRY(hipStreamWaitEvent(P[1].main, c->evStart, 0));
+            for (int k = 1; k < parts; k++) HIP_TRY(hipStreamWaitEvent(P[k].main, c->evStart, 0));
         }
         int live = 0;
         for (int k = 0; k < parts; k++) {
@@ -1419,9 +1423,9 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
                 else wf_iteration<false>(P[k], traceBlocks);
             }
         }
-        if (parts > 1) {
-            HIP_TRY(hipEventRecord(c->evDone, P[1].main));
-            HIP_TRY(hipStreamWaitEvent(s, c->evDone, 0));
+        for (int k = 1; k < parts; k++) {
+            HIP_TRY(hipEventRecord(c->evDone[k], P[k].main));
+            HIP_TRY(hipStreamWaitEvent(s, c->evDone[k], 0));
         }
     }
     hipError_t le = hipGetLastError();
