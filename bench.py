@@ -47,6 +47,22 @@ def algorithmic_bytes(st):
     return 32 * st["nBox"] + 40 * st["nTri"] + 112 * st["nHit"] + 16 * st["nTap"] + 12 * st["nPx"]
 
 
+def pmc_traffic(workload, world):
+    """(bytes per frame, None, source) from the newest committed PMC summary of this workload; (None, None, None) otherwise."""
+    if world != 1:
+        return None, None, None
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload:
+            best = (float(d["traffic_bytes_per_frame"]), None, "profiles/" + os.path.basename(f))
+    return best if best else (None, None, None)
+
+
 def host_cores():
     """Cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box hands a
     1-GPU job a share of the host, not all of os.cpu_count())."""
@@ -207,6 +223,11 @@ def main():
         ct = tracer.stats()
         B = algorithmic_bytes(ct)
         achieved = B / (kernel_ms * 1e-3) / 1e9
+        # HBM-side bytes of one launch: not measurable from inside the process; taken from the committed PMC passes of this
+        # same workload (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, guide corrections)
+        traffic_bytes, traffic_rate, traffic_src = pmc_traffic(args.workload, world)
+        if traffic_bytes is not None:
+            traffic_rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9
         value = rays_per_step * args.steps / dt / 1e6
         name, cus = tracer.device_info()
         out = {
@@ -219,7 +240,7 @@ def main():
                        "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL sum-reduce image gather" if world > 1
                        else "one GPU", "device": name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "wavefront pipeline of one frame: shade_kernel + trace_kernel<0..3>, (spp/8)*(1+depth)+1 iterations", "kernel_ms": kernel_ms,
+                         "traffic": traffic_rate, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "kernel": "wavefront pipeline of one frame: shade_kernel + trace_kernel<0..3>, (spp/8)*(1+depth)+1 iterations", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": int(B),
                          "events_per_launch": {k: ct[k] for k in ("nBox", "nTri", "nHit", "nTap", "nPx")}},
         }
