@@ -980,6 +980,10 @@ int prt_hip_device_count(void)
 int prt_hip_create(int device, prt_hip_ctx** out)
 {
     if (!out) return fail(PRT_HIP_EINVAL, "out is NULL");
+    // Four streams of this library run side by side; when the host process owns more streams (RCCL, a framework) the HIP
+    // runtime's default of four hardware queues makes them share.  Only read when the runtime initialises -- a no-op if the
+    // host already made a HIP call, and never overrides the host's own setting.
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
         return fail(PRT_HIP_ENODEVICE, "no HIP device: libprt_hip has no CPU path (the GPU kernels are the product)");
