@@ -118,6 +118,12 @@ struct orc_scene {
     float radius;
     texture_t* textures;
     int32_t textureCount;
+    /* InfiniteAreaLight (light.h:28-50): float RGBA image + the two CDF tables */
+    int hasEnv;
+    int32_t envWidth, envHeight;
+    float* envTexels;      /* 4 floats per texel (Texture::loadExr: component = 4, texture.cpp:304) */
+    float* envVerticalP;   /* [height] */
+    float* envHorizontalP; /* [width*height] */
 };
 
 static void bbox_init(v3* lo, v3* hi) { *lo = v3s(FLT_MAX); *hi = v3s(-FLT_MAX); } /* vecmath.cpp:46 */
@@ -396,6 +402,7 @@ void orc_scene_destroy(orc_scene* s)
     if (!s) return;
     for (uint32_t i = 0; i < s->bvhCount; i++) orc_bvh_destroy(s->bvh[i]);
     for (int32_t i = 0; i < s->textureCount; i++) free(s->textures[i].texels);
+    free(s->envTexels); free(s->envVerticalP); free(s->envHorizontalP);
     free(s->textures); free(s->bvh); free(s);
 }
 
@@ -415,6 +422,54 @@ void orc_scene_set_directional_light(orc_scene* s, const float dir[3], const flo
     s->lightDir = ld3(dir);
     s->lightIntensity = ld3(intensity);
 }
+
+/* InfiniteAreaLight::create, light.cpp:30-84, from float RGBA texels instead of an .exr file (scene.h:42-45 sets the
+ * kInfiniteArea bit, which ComputeRadiance tests BEFORE the directional light, path_tracer.cpp:164-173) */
+void orc_scene_set_env_light(orc_scene* s, int32_t width, int32_t height, const float* rgba)
+{
+    free(s->envTexels); free(s->envVerticalP); free(s->envHorizontalP);
+    size_t n = (size_t)width * (size_t)height;
+    s->envTexels = (float*)malloc(n * 4 * sizeof(float));
+    memcpy(s->envTexels, rgba, n * 4 * sizeof(float));
+    s->envWidth = width; s->envHeight = height;
+    s->envVerticalP = (float*)malloc((size_t)height * sizeof(float));
+    s->envHorizontalP = (float*)malloc(n * sizeof(float));
+    float* vert = s->envVerticalP;
+    float* hori = s->envHorizontalP;
+    const float* p = s->envTexels;
+    float vsum = 0.0f;
+    for (uint32_t y = 0; y < (uint32_t)height; y++) {
+        float hsum = 0.0f;
+        for (uint32_t x = 0; x < (uint32_t)width; x++) {
+            uint32_t indexBase = x + y * (uint32_t)width;
+            float l = length3(V3(p[4 * indexBase + 0], p[4 * indexBase + 1], p[4 * indexBase + 2]));
+            hori[indexBase] = l;
+            hsum += l;
+        }
+        float sinPhi = sinf(kPi * ((float)y + 0.5f) / (float)height); /* :58 */
+        vert[y] = hsum * sinPhi;
+        vsum += hsum * sinPhi;
+        float invH = 1.0f / hsum;
+        float accumH = 0.0f;
+        for (uint32_t x = 0; x < (uint32_t)width; x++) {
+            uint32_t indexBase = x + y * (uint32_t)width;
+            float ph = accumH + invH * hori[indexBase];
+            hori[indexBase] = ph;
+            accumH = ph;
+        }
+    }
+    float invV = 1.0f / vsum;
+    float accumV = 0.0f;
+    for (uint32_t y = 0; y < (uint32_t)height; y++) {
+        float pv = accumV + invV * vert[y];
+        vert[y] = pv;
+        accumV = pv;
+    }
+    s->hasEnv = 1;
+}
+
+const float* orc_scene_env_vertical(const orc_scene* s) { return s->envVerticalP; }
+const float* orc_scene_env_horizontal(const orc_scene* s) { return s->envHorizontalP; }
 
 int32_t orc_scene_add_texture(orc_scene* s, int32_t width, int32_t height, int32_t component, const uint8_t* texels)
 {
@@ -1242,6 +1297,81 @@ uint32_t orc_occluded_packet(const orc_scene* s, uint32_t activeMask, const floa
     return occludeMask;
 }
 
+/* Texture::sample<Vector3f, float>, texture.cpp:102-139: scalar bilinear helper, c = c + k[i]*rgb, returned unscaled */
+static v3 tex_sample3f(const float* texels, int32_t width, int32_t height, int32_t component, v2 uv, orc_stats* st)
+{
+    float k[4];
+    int32_t idx[4];
+    bilinear(k, idx, component, uv, width, height, 0);
+    if (st) st->nTap++;
+    v3 c = v3s(0.0f);
+    for (int i = 0; i < 4; i++) {
+        const float* p = texels + idx[i];
+        c = add3(c, scale3(k[i], V3(p[0], p[1], p[2])));
+    }
+    return c;
+}
+
+void orc_x_tex_sample3f(int32_t w, int32_t h, int32_t comp, const float* texels, float u, float v, float out[3])
+{
+    st3(out, tex_sample3f(texels, w, h, comp, V2(u, v), NULL));
+}
+
+/* ------------------------------------------------------------------ InfiniteAreaLight::sample, light.cpp:86-128
+ * Texture::sample<Vector3f> on k32Float texels (texture.cpp:88-139): the scalar bilinear helper, c += k[i]*rgb, no scale.
+ * Defined where the reference is undefined: when no vertical CDF entry exceeds u.y the reference leaves y == m_height and
+ * reads m_horizontalP one row past its end (:110-112); here that row is treated as "no entry exceeds u.x" (xf = 0,
+ * pdfH = 1), which is what finite heap garbage below u.x would give. */
+static void env_sample(const orc_scene* s, float ux, float uy, v3* dir, v3* color, orc_stats* st)
+{
+    const int32_t W = s->envWidth, H = s->envHeight;
+    const float* vp = s->envVerticalP;
+    const float* hp = s->envHorizontalP;
+    int32_t y;
+    float pdfV = 1.0f, yf = 0.0f;
+    for (y = 1; y < H; y++) {
+        if (vp[y] > uy) {
+            float prev = vp[y - 1];
+            float pdf = vp[y] - prev;
+            if (pdf == 0.0f) continue;
+            pdfV = pdf;
+            yf = (float)y + (uy - prev) / pdfV - 1.0f;
+            break;
+        }
+    }
+    float pdfH = 1.0f, xf = 0.0f;
+    if (y < H) {
+        for (int32_t x = 1; x < W; x++) {
+            if (hp[x + y * W] > ux) {
+                float prev = hp[x - 1 + y * W];
+                float pdf = hp[x + y * W] - prev;
+                if (pdf == 0.0f) continue;
+                pdfH = pdf;
+                xf = (float)x + (ux - prev) / pdfH - 1.0f;
+                break;
+            }
+        }
+    }
+    v2 uv = V2(xf / (float)W, yf / (float)H);
+    v3 c = tex_sample3f(s->envTexels, W, H, 4, uv, st);
+    c = div3(div3(c, v3s(pdfH * pdfV)), v3s((float)(W * H))); /* :118: Vector3f / Vector3f(float), vecmath.h:263 */
+    float theta = 2.0f * kPi * (uv.x + 0.5f);
+    float phi = kPi * uv.y;
+    float sinPhi = sinf(phi);
+    *dir = normalize3(V3(cosf(theta) * sinPhi, cosf(phi), sinf(theta) * sinPhi));
+    *color = c;
+}
+
+void orc_x_env_sample(const orc_scene* s, uint32_t n, const float* u, float* dirOut, float* colorOut)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        v3 d, c;
+        env_sample(s, u[2 * i], u[2 * i + 1], &d, &c, NULL);
+        st3(dirOut + 3 * i, d);
+        st3(colorOut + 3 * i, c);
+    }
+}
+
 /* ------------------------------------------------------------------ camera.cpp:35-73 */
 static void camera_packet(const orc_camera* cam, uint32_t* rng, uint32_t x, uint32_t y, float org[LANES][3],
                           float dir[LANES][3], float avgDirOut[3], orc_stats* st)
@@ -1325,7 +1455,12 @@ static v3 compute_radiance(const orc_scene* scene, uint32_t* rng, const orc_hit 
                 float r1 = rng_f(rng, st);
                 nextRayDir[path] = diffuse_dir(normal, r2, r1);
                 beta[path] = mul3(beta[path], sample_diffuse(scene, material, prop.uv, st));
-                if (scene->hasDirectional) {
+                if (scene->hasEnv) { /* path_tracer.cpp:164-167; argument evaluation left to right (clang) */
+                    float ux = rng_f(rng, st);
+                    float uy = rng_f(rng, st);
+                    env_sample(scene, ux, uy, &lightDir[path], &lightIntensity[path], st);
+                    directLighting = 1;
+                } else if (scene->hasDirectional) {
                     lightDir[path] = scene->lightDir;
                     lightIntensity[path] = scene->lightIntensity;
                     directLighting = 1;

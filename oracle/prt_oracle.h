@@ -99,6 +99,12 @@ void orc_scene_destroy(orc_scene*); /* destroys added bvhs */
 void orc_scene_add(orc_scene*, orc_bvh*);
 void orc_scene_set_directional_light(orc_scene*, const float dir[3], const float intensity[3]);
 int32_t orc_scene_add_texture(orc_scene*, int32_t width, int32_t height, int32_t component, const uint8_t* texels);
+/* InfiniteAreaLight::create (light.cpp:30-84) from float RGBA texels; sample (light.cpp:86-128) for n (u.x, u.y) pairs */
+void orc_scene_set_env_light(orc_scene*, int32_t width, int32_t height, const float* rgba);
+const float* orc_scene_env_vertical(const orc_scene*);
+const float* orc_scene_env_horizontal(const orc_scene*);
+void orc_x_env_sample(const orc_scene*, uint32_t n, const float* u, float* dirOut, float* colorOut);
+void orc_x_tex_sample3f(int32_t w, int32_t h, int32_t comp, const float* texels, float u, float v, float out[3]);
 float orc_scene_radius(const orc_scene*);
 const float* orc_scene_bbox(const orc_scene*);
 

@@ -122,6 +122,38 @@ SoaMask Texture::testAlpha(const SoaMask& mask, const SoaVector2f& uv) const
     return SoaMask(res);
 }
 
+// ---- what light.cpp (built from the reference, InfiniteAreaLight::create/sample) needs from texture.cpp
+// texture.cpp:88-139, k32Float branch
+template <>
+Vector3f Texture::sample<Vector3f>(const Vector2f& uv) const
+{
+    if (channel != TextureChannel::k32Float) { fprintf(stderr, "ref_glue: sample<Vector3f> on a non-float texture\n"); abort(); }
+    Vector3f out;
+    orc_x_tex_sample3f(width, height, component, (const float*)texels, uv.x, uv.y, &out.x);
+    return out;
+}
+
+// texture.cpp:256-310 decodes an OpenEXR file with tinyexr (not in this image).  The harness hands the float RGBA texels
+// over in a raw file instead -- "PRTE", i32 width, i32 height, width*height*4 f32 -- and this keeps the field bookkeeping
+// of :303-310 (component 4, k32Float).
+void Texture::loadExr(const char* path)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "ref_glue: cannot open %s\n", path); abort(); }
+    char magic[4];
+    int32_t w = 0, h = 0;
+    if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "PRTE", 4) || fread(&w, 4, 1, f) != 1 || fread(&h, 4, 1, f) != 1) abort();
+    float* p = (float*)malloc((size_t)w * h * 16);
+    if (fread(p, 16, (size_t)w * h, f) != (size_t)w * h) abort();
+    fclose(f);
+    texels = p;
+    component = 4;
+    width = w;
+    height = h;
+    format = 0;
+    channel = TextureChannel::k32Float;
+}
+
 // ---- what sample_models.cpp needs to hand over the Cornell box data (mesh.cpp:23-104, 302-309;
 // material.cpp:30-43; texture.cpp:202-210): allocation and field bookkeeping only.
 void Texture::init()

@@ -470,11 +470,12 @@ static int cmdCamera(const char* scenePath, uint32_t x, uint32_t y, uint32_t sta
 // out: f32 rgb[(x1-x0+1)*(y1-y0+1)*3] row-major over the rectangle, then u64 raysTraced, u64 occludedTraced
 // (zero unless built with PRT_ENABLE_STATS), then f64 seconds
 static int cmdRender(const char* scenePath, uint32_t spp, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t seed,
-                     int threads, const char* out)
+                     int threads, const char* out, const char* envPath)
 {
     FScene fs = loadScene(scenePath);
     RefScene r = buildRef(fs);
     refGlueRegister(r.bvhs, r.omeshes);
+    if (envPath) r.scene->setInfiniteAreaLight(envPath); // scene.h:42-45 -> InfiniteAreaLight::create (light.cpp:30-84)
     const uint32_t W = fs.width, H = fs.height;
     Image* image = refGlueMakeImage(W, H, fs.exposure);
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
@@ -520,6 +521,34 @@ static int cmdRender(const char* scenePath, uint32_t spp, uint32_t x0, uint32_t 
     return 0;
 }
 
+// ------------------------------------------------------------------ InfiniteAreaLight::create + sample (light.cpp:30-128)
+// in: env file (see ref_glue.cpp Texture::loadExr), u file = f32 pairs (u.x, u.y)
+// out: i32 width, i32 height, f32 verticalP[height], f32 horizontalP[width*height], then per pair f32 dir[3], color[3]
+static int cmdEnvLight(const char* envPath, const char* uPath, const char* out)
+{
+    InfiniteAreaLight light;
+    light.init();
+    light.create(envPath);
+    std::vector<float> uv = readFloats(uPath);
+    const float* u = uv.data();
+    size_t n = uv.size() / 2;
+    std::vector<float> o;
+    int32_t wh[2] = {light.m_width, light.m_height};
+    float tmp[2];
+    memcpy(tmp, wh, 8);
+    o.push_back(tmp[0]); o.push_back(tmp[1]);
+    o.insert(o.end(), light.m_verticalP, light.m_verticalP + light.m_height);
+    o.insert(o.end(), light.m_horizontalP, light.m_horizontalP + (size_t)light.m_width * light.m_height);
+    for (size_t i = 0; i < n; i++) {
+        Vector3f dir, color;
+        light.sample(dir, color, Vector2f(u[2 * i], u[2 * i + 1]));
+        float rec[6] = {dir.x, dir.y, dir.z, color.x, color.y, color.z};
+        o.insert(o.end(), rec, rec + 6);
+    }
+    writeAll(out, o.data(), o.size() * 4);
+    return 0;
+}
+
 // Cornell box data as the reference's SampleModels::getCornellBox builds it (sample_models.cpp:11-207):
 // out: u32 primCount, vertexCount, materialCount; u32 indices[]; f32 positions[]; u32 primMaterial[]; materials as orc_material
 static int cmdCornell(const char* out)
@@ -558,7 +587,8 @@ int main(int argc, char** argv)
 #ifdef REF_WITH_GLUE
     if (argc >= 11 && !strcmp(argv[1], "render"))
         return cmdRender(argv[2], (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), (uint32_t)atoi(argv[5]), (uint32_t)atoi(argv[6]),
-                         (uint32_t)atoi(argv[7]), (uint32_t)strtoul(argv[8], 0, 10), atoi(argv[9]), argv[10]);
+                         (uint32_t)atoi(argv[7]), (uint32_t)strtoul(argv[8], 0, 10), atoi(argv[9]), argv[10], argc >= 12 ? argv[11] : nullptr);
+    if (argc >= 5 && !strcmp(argv[1], "envlight")) return cmdEnvLight(argv[2], argv[3], argv[4]);
     if (argc >= 3 && !strcmp(argv[1], "cornell")) return cmdCornell(argv[2]);
 #endif
     fprintf(stderr,

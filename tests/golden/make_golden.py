@@ -218,6 +218,26 @@ def dump_radiance():
                         cornell_only_rays=np.array([st2["raysTraced"], st2["occludedTraced"]], dtype=np.uint64))
 
 
+def dump_env_light():
+    # InfiniteAreaLight::create + sample of the compiled reference (light.cpp:30-128) on two seeded maps, and a Cornell-only
+    # render lit by the first (pins the two extra generator draws per diffuse bounce, path_tracer.cpp:164-167)
+    out = {}
+    for name, (w, h, black) in {"sky": (64, 32, False), "black_rows": (48, 24, True)}.items():
+        desc = T.cornell_scene(96, 96, with_teapot=False)
+        desc.env = T.sky_env(w, h, black_rows=black)
+        u = T.env_test_u(4096)
+        vp, hp, d, c = T.ref_envlight(desc, u)
+        out.update({f"{name}_size": np.array([w, h, int(black)]), f"{name}_vertical": vp, f"{name}_horizontal": hp,
+                    f"{name}_dir": d, f"{name}_color": c})
+    desc = T.cornell_scene(96, 96, with_teapot=False)
+    desc.env = T.sky_env(64, 32)
+    rect = (16, 16, 79, 79)
+    rgb, st = T.ref_render(desc, 16, rect, seed=12345, stats=True)
+    print("env-lit cornell crop mean", rgb.reshape(-1, 3).mean(0), st)
+    np.savez_compressed(os.path.join(HERE, "env_light.npz"), rect=np.array(rect), rgb=rgb,
+                        rays=np.array([st["raysTraced"], st["occludedTraced"]], dtype=np.uint64), **out)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", T.ORACLE_DIR])
     dump_cornell()
@@ -225,3 +245,4 @@ if __name__ == "__main__":
     dump_leaf()
     dump_scene_vectors()
     dump_radiance()
+    dump_env_light()

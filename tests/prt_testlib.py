@@ -131,6 +131,10 @@ def oracle():
                              C.POINTER(OrcStats)]
     L.orc_max_threads.restype = C.c_int
     L.orc_render_rect.argtypes = [vp, C.POINTER(OrcCamera)] + [C.c_uint32] * 7 + [C.c_float, C.c_int, vp, C.POINTER(OrcStats)]
+    L.orc_scene_set_env_light.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    L.orc_scene_set_env_light.restype = None
+    L.orc_x_env_sample.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.orc_x_env_sample.restype = None
     L.orc_set_anyhit_accounting.argtypes = [C.c_int]
     L.orc_set_anyhit_accounting.restype = None
     L.orc_libm_sincos.argtypes = [C.c_uint32, vp, vp, vp]
@@ -185,7 +189,7 @@ def make_material(diffuse=(0, 0, 0), emissive=(0, 0, 0), reflection=0, alpha_tes
 
 
 class SceneDesc:
-    def __init__(self, meshes, cam_pos, cam_dir, width, height, light=None, textures=(), exposure=1.0):
+    def __init__(self, meshes, cam_pos, cam_dir, width, height, light=None, textures=(), exposure=1.0, env=None):
         self.meshes = list(meshes)
         self.cam_pos = np.asarray(cam_pos, dtype=np.float32)
         self.cam_dir = np.asarray(cam_dir, dtype=np.float32)
@@ -193,6 +197,15 @@ class SceneDesc:
         self.light = light  # (dir[3], intensity[3]) or None
         self.textures = list(textures)  # uint8 arrays (h, w, comp)
         self.exposure = float(exposure)
+        self.env = None if env is None else np.ascontiguousarray(env, dtype=np.float32)  # (h, w, 4) float RGBA environment map
+
+    def write_env(self, path):
+        """The raw float environment map the reference harness reads in place of an .exr (oracle/ref_glue.cpp)."""
+        h, w, _ = self.env.shape
+        with open(path, "wb") as f:
+            f.write(b"PRTE")
+            f.write(struct.pack("<ii", w, h))
+            f.write(self.env.astype("<f4").tobytes())
 
     def write_prts(self, path):
         with open(path, "wb") as f:
@@ -244,6 +257,9 @@ class OracleScene:
             L.orc_scene_add(self.scene, b)
         if desc.light is not None:
             L.orc_scene_set_directional_light(self.scene, f3(desc.light[0]), f3(desc.light[1]))
+        if desc.env is not None:
+            h, w, _ = desc.env.shape
+            L.orc_scene_set_env_light(self.scene, w, h, vptr(desc.env))
         self.camera = OrcCamera()
         L.orc_camera_create(C.byref(self.camera), f3(desc.cam_pos), f3(desc.cam_dir), desc.width, desc.height)
 
@@ -257,6 +273,23 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def env_tables(self):
+        h, w, _ = self.desc.env.shape
+        self.L.orc_scene_env_vertical.restype = C.POINTER(C.c_float)
+        self.L.orc_scene_env_horizontal.restype = C.POINTER(C.c_float)
+        self.L.orc_scene_env_vertical.argtypes = [C.c_void_p]
+        self.L.orc_scene_env_horizontal.argtypes = [C.c_void_p]
+        v = np.ctypeslib.as_array(self.L.orc_scene_env_vertical(self.scene), shape=(h,)).copy()
+        hh = np.ctypeslib.as_array(self.L.orc_scene_env_horizontal(self.scene), shape=(h * w,)).copy()
+        return v, hh
+
+    def env_sample(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
+        d = np.zeros((len(u), 3), dtype=np.float32)
+        c = np.zeros((len(u), 3), dtype=np.float32)
+        self.L.orc_x_env_sample(self.scene, len(u), vptr(u), vptr(d), vptr(c))
+        return d, c
 
     def nodes(self, i):
         n = self.L.orc_bvh_node_count(self.bvhs[i])
@@ -386,12 +419,33 @@ def ref_bvh(desc, threaded=False):
     return out, sbox, radius
 
 
+def ref_envlight(desc, u):
+    """InfiniteAreaLight::create + sample of the compiled reference: (verticalP, horizontalP, dir, color)."""
+    u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 2)
+    with tempfile.TemporaryDirectory() as td:
+        ep, up, op = os.path.join(td, "e.prte"), os.path.join(td, "u.bin"), os.path.join(td, "out.bin")
+        desc.write_env(ep)
+        u.astype("<f4").tofile(up)
+        run_ref("ref_path", "envlight", ep, up, op)
+        raw = np.fromfile(op, dtype="<f4")
+    w, h = (int(v) for v in raw[:2].view(np.int32))
+    vp = raw[2:2 + h].copy()
+    hp = raw[2 + h:2 + h + w * h].copy()
+    rec = raw[2 + h + w * h:].reshape(-1, 6)
+    return vp, hp, rec[:, :3].copy(), rec[:, 3:].copy()
+
+
 def ref_render(desc, spp, rect, seed=12345, threads=0, stats=True):
     x0, y0, x1, y1 = rect
     with tempfile.TemporaryDirectory() as td:
         sp, op = os.path.join(td, "s.prts"), os.path.join(td, "out.bin")
         desc.write_prts(sp)
-        run_ref("ref_path_stats" if stats else "ref_path", "render", sp, spp, x0, y0, x1, y1, seed, threads, op)
+        extra = []
+        if desc.env is not None:
+            ep = os.path.join(td, "e.prte")
+            desc.write_env(ep)
+            extra = [ep]
+        run_ref("ref_path_stats" if stats else "ref_path", "render", sp, spp, x0, y0, x1, y1, seed, threads, op, *extra)
         raw = open(op, "rb").read()
     n = (x1 - x0 + 1) * (y1 - y0 + 1) * 3
     rgb = np.frombuffer(raw, dtype="<f4", count=n).reshape(y1 - y0 + 1, x1 - x0 + 1, 3).copy()
@@ -437,6 +491,41 @@ def cornell_scene(width, height, with_teapot=True):
     if with_teapot:
         meshes.append(oracle_vertex_normals(load_teapot_mesh()))
     return SceneDesc(meshes, cam_pos=(0, 0.965, 2.6), cam_dir=(0, 0, -1.0), width=width, height=height)
+
+
+def sky_env(w, h, seed=7, black_rows=False):
+    """Seeded procedural float RGBA environment map (h, w, 4): gradient sky, a bright sun blob, per-texel noise.
+    black_rows adds all-black rows and columns (zero-pdf entries, NaN rows in the horizontal CDF, light.cpp:63-71)."""
+    rng = np.random.default_rng(seed)
+    y = (np.arange(h) + 0.5) / h
+    x = (np.arange(w) + 0.5) / w
+    e = np.zeros((h, w, 4), dtype=np.float32)
+    e[..., 0] = 0.3 + 0.5 * (1 - y)[:, None]
+    e[..., 1] = 0.4 + 0.4 * (1 - y)[:, None]
+    e[..., 2] = 0.9 * (1 - 0.5 * y)[:, None]
+    sun = np.exp(-(((x[None, :] - 0.3) * 6) ** 2 + ((y[:, None] - 0.25) * 6) ** 2))
+    e[..., :3] += (40.0 * sun)[..., None].astype(np.float32)
+    e[..., :3] *= rng.uniform(0.5, 1.5, size=(h, w, 1)).astype(np.float32)
+    if black_rows:
+        e[h // 2:, :, :3] = 0.0
+        e[1, :, :3] = 0.0
+        e[:, : w // 8, :3] = 0.0
+    e[..., 3] = 1.0
+    return e
+
+
+def env_test_u(n, seed=11):
+    """(u.x, u.y) pairs for InfiniteAreaLight::sample incl. the ends of [0, 1)."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, 2)).astype(np.float32)
+    top = np.float32(0.99999994)
+    u[:64] = top
+    u[64:128, 0] = 0.0
+    u[128:192, 1] = 0.0
+    u[192:224] = 0.0
+    u[224:256, 0] = top
+    u[256:288, 1] = top
+    return u
 
 
 def scene_desc_from_product(scene, camera, exposure=1.0):
