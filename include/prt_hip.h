@@ -89,6 +89,14 @@ typedef struct {
     float lightDir[3];
     float lightIntensity[3];
     float radius;                 /* Scene::getRadius() */
+    /* InfiniteAreaLight (light.h:28-50), tested before the directional light (path_tracer.cpp:164-173): the float RGBA
+     * image (Texture::loadExr: 4 floats per texel, row 0 first) and the two CDF tables InfiniteAreaLight::create builds
+     * (light.cpp:30-84).  The library copies all three. */
+    uint32_t hasInfiniteAreaLight; /* Scene::isLightAvailable(kInfiniteArea) */
+    int32_t envWidth, envHeight;
+    const float* envTexels;        /* 4*envWidth*envHeight */
+    const float* envVerticalP;     /* m_verticalP[envHeight] */
+    const float* envHorizontalP;   /* m_horizontalP[envWidth*envHeight] */
 } prt_scene_desc;
 
 /* Camera after Camera::create (camera.h:17-36, 46-53). */

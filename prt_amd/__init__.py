@@ -64,7 +64,9 @@ class TextureDesc(C.Structure):
 class SceneDesc(C.Structure):
     _fields_ = [("meshCount", C.c_uint32), ("meshes", C.POINTER(MeshDesc)), ("textureCount", C.c_uint32),
                 ("textures", C.POINTER(TextureDesc)), ("hasDirectionalLight", C.c_uint32), ("lightDir", C.c_float * 3),
-                ("lightIntensity", C.c_float * 3), ("radius", C.c_float)]
+                ("lightIntensity", C.c_float * 3), ("radius", C.c_float),
+                ("hasInfiniteAreaLight", C.c_uint32), ("envWidth", C.c_int32), ("envHeight", C.c_int32),
+                ("envTexels", C.POINTER(C.c_float)), ("envVerticalP", C.POINTER(C.c_float)), ("envHorizontalP", C.POINTER(C.c_float))]
 
 
 class CameraDesc(C.Structure):
@@ -107,7 +109,7 @@ EXPORTS = [
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
     "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
     "prt_host_mesh_calculate_bounds", "prt_host_mesh_prim_count", "prt_host_scene_create", "prt_host_scene_destroy",
-    "prt_host_scene_add_mesh", "prt_host_scene_set_directional_light", "prt_host_scene_describe", "prt_host_scene_bbox",
+    "prt_host_scene_add_mesh", "prt_host_scene_set_directional_light", "prt_host_scene_set_env_light", "prt_host_scene_load_env_light", "prt_host_scene_describe", "prt_host_scene_bbox",
     "prt_host_camera_create", "prt_host_bvh_build", "prt_host_free",
 ]
 
@@ -169,6 +171,9 @@ def lib():
     L.prt_host_scene_add_mesh.argtypes = [vp, vp]
     L.prt_host_scene_set_directional_light.argtypes = [vp, f32p, f32p]
     L.prt_host_scene_set_directional_light.restype = None
+    L.prt_host_scene_set_env_light.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    L.prt_host_scene_set_env_light.restype = None
+    L.prt_host_scene_load_env_light.argtypes = [vp, C.c_char_p]
     L.prt_host_scene_describe.argtypes = [vp]
     L.prt_host_scene_describe.restype = C.POINTER(SceneDesc)
     L.prt_host_scene_bbox.argtypes = [vp, f32p]
@@ -261,6 +266,16 @@ class Scene:
     def set_directional_light(self, direction, intensity):
         lib().prt_host_scene_set_directional_light(self._h, _f3(direction), _f3(intensity))
 
+    def set_infinite_area_light(self, env):
+        """Scene::setInfiniteAreaLight (scene.h:42-45): `env` is a path to an RGB PFM file or a float array (h, w, 4) RGBA, row 0 = top."""
+        if isinstance(env, (str, bytes, os.PathLike)):
+            _check(lib().prt_host_scene_load_env_light(self._h, os.fsencode(env)), "prt_host_scene_load_env_light")
+            return
+        e = np.ascontiguousarray(env, dtype=np.float32)
+        if e.ndim != 3 or e.shape[2] != 4:
+            raise PrtError("environment map must be (height, width, 4) float RGBA")
+        lib().prt_host_scene_set_env_light(self._h, e.shape[1], e.shape[0], e.ctypes.data_as(C.c_void_p))
+
     def describe(self):
         return lib().prt_host_scene_describe(self._h)
 
@@ -289,6 +304,12 @@ class Scene:
         for i in range(d.textureCount):
             t = d.textures[i]
             out["textures"].append(np.ctypeslib.as_array(t.texels, shape=(t.height, t.width, t.component)).copy())
+        out["env"] = None
+        if d.hasInfiniteAreaLight:
+            w, h = d.envWidth, d.envHeight
+            out["env"] = np.ctypeslib.as_array(d.envTexels, shape=(h, w, 4)).copy()
+            out["env_vertical"] = np.ctypeslib.as_array(d.envVerticalP, shape=(h,)).copy()
+            out["env_horizontal"] = np.ctypeslib.as_array(d.envHorizontalP, shape=(h * w,)).copy()
         return out
 
     def __del__(self):

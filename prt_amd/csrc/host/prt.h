@@ -174,6 +174,27 @@ struct DirectionalLight {
     Vector3f dir, intensity;
 };
 
+// ---- light.h:28-50: the image and the CDF tables; sampling (light.cpp:86-128) runs in the kernels ----
+class InfiniteAreaLight
+{
+public:
+    void init();
+    void create(const char* path); // a PFM file here (light.cpp:32 reads an .exr through tinyexr)
+    void create(int32_t width, int32_t height, const float* rgba); // light.cpp:34-84 on texels already in memory
+    void release();
+    bool isValid() const { return !m_texels.empty(); }
+    int32_t getWidth() const { return m_width; }
+    int32_t getHeight() const { return m_height; }
+    const std::vector<float>& getTexels() const { return m_texels; }
+    const std::vector<float>& getVerticalP() const { return m_verticalP; }
+    const std::vector<float>& getHorizontalP() const { return m_horizontalP; }
+
+private:
+    std::vector<float> m_texels; // RGBA float, row 0 first (Texture::loadExr, texture.cpp:303-310)
+    std::vector<float> m_verticalP, m_horizontalP;
+    int32_t m_width = 0, m_height = 0;
+};
+
 // ---- scene.h:11-73 ----
 class Scene
 {
@@ -183,7 +204,9 @@ public:
     bool isLightAvailable(LightType type) const { return (m_availableLights & (1u << (uint32_t)type)) != 0; }
     void setDirectionalLight(const Vector3f& dir, const Vector3f& intensity);
     const DirectionalLight& getDirectionalLight() const { return m_directionalLight; }
-    void setInfiniteAreaLight(const char* path); // not on this path yet: reports and ignores
+    void setInfiniteAreaLight(const char* path);                                   // scene.h:42-45
+    void setInfiniteAreaLight(int32_t width, int32_t height, const float* rgba);   // same, texels already in memory
+    const InfiniteAreaLight& getInfiniteAreaLight() const { return m_infiniteAreaLight; }
     float getRadius() const { return m_radius; }
     const BBox& getBBox() const { return m_bbox; }
     const std::vector<Bvh*>& getBvhs() const { return m_bvh; }
@@ -202,6 +225,7 @@ private:
     std::vector<Bvh*> m_bvh;
     uint32_t m_availableLights = 0;
     DirectionalLight m_directionalLight;
+    InfiniteAreaLight m_infiniteAreaLight;
     BBox m_bbox;
     float m_radius = 0.0f;
     uint64_t m_revision = 0;

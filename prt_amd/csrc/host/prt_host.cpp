@@ -117,6 +117,7 @@ void Mesh::calculateBounds() // mesh.cpp:302-309
 void Scene::init()
 {
     m_directionalLight.init();
+    m_infiniteAreaLight.init();
     m_availableLights = 0;
     m_bbox = BBox::init();
     m_radius = std::numeric_limits<float>::max();
@@ -142,9 +143,119 @@ void Scene::setDirectionalLight(const Vector3f& dir, const Vector3f& intensity) 
     m_revision++;
 }
 
-void Scene::setInfiniteAreaLight(const char* path)
+void Scene::setInfiniteAreaLight(const char* path) // scene.h:42-45
 {
-    logPrintf(LogLevel::kError, "InfiniteAreaLight '%s' is not on the GPU path yet (SURVEY.md 8f.1); ignored\n", path);
+    m_infiniteAreaLight.create(path);
+    if (!m_infiniteAreaLight.isValid()) return;
+    m_availableLights |= (1u << (uint32_t)LightType::kInfiniteArea);
+    m_revision++;
+}
+
+void Scene::setInfiniteAreaLight(int32_t width, int32_t height, const float* rgba)
+{
+    m_infiniteAreaLight.create(width, height, rgba);
+    if (!m_infiniteAreaLight.isValid()) return;
+    m_availableLights |= (1u << (uint32_t)LightType::kInfiniteArea);
+    m_revision++;
+}
+
+// ---- light.cpp:13-84 ----
+static const float kPi = 3.14159265358979323846f; // vecmath.h:162
+void InfiniteAreaLight::init() { release(); }
+
+void InfiniteAreaLight::release()
+{
+    m_texels.clear();
+    m_verticalP.clear();
+    m_horizontalP.clear();
+    m_width = m_height = 0;
+}
+
+// The reference decodes an OpenEXR file (texture.cpp:256-310, tinyexr).  This build reads a PFM ("PF", width height, scale;
+// rows bottom to top, RGB float32; a negative scale means little-endian) into the same RGBA float layout, row 0 = top.
+void InfiniteAreaLight::create(const char* path)
+{
+    release();
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        logPrintf(LogLevel::kError, "Failed to open '%s'\n", path);
+        return;
+    }
+    char magic[3] = {0, 0, 0};
+    int w = 0, h = 0;
+    float scale = 0.0f;
+    if (fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || strcmp(magic, "PF") != 0 || w <= 0 || h <= 0 || scale == 0.0f) {
+        logPrintf(LogLevel::kError, "'%s' is not an RGB PFM file\n", path);
+        fclose(f);
+        return;
+    }
+    fgetc(f); // the single whitespace after the header
+    std::vector<float> rgb((size_t)w * h * 3);
+    size_t got = fread(rgb.data(), sizeof(float), rgb.size(), f);
+    fclose(f);
+    if (got != rgb.size()) {
+        logPrintf(LogLevel::kError, "'%s' is truncated\n", path);
+        return;
+    }
+    if (scale > 0.0f) // big-endian samples
+        for (float& v : rgb) {
+            uint32_t u;
+            memcpy(&u, &v, 4);
+            u = (u >> 24) | ((u >> 8) & 0xff00u) | ((u << 8) & 0xff0000u) | (u << 24);
+            memcpy(&v, &u, 4);
+        }
+    std::vector<float> rgba((size_t)w * h * 4);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float* s = &rgb[((size_t)(h - 1 - y) * w + x) * 3];
+            float* d = &rgba[((size_t)y * w + x) * 4];
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 1.0f;
+        }
+    logPrintf(LogLevel::kVerbose, "Loaded .pfm '%s' (%d, %d)\n", path, w, h);
+    create(w, h, rgba.data());
+}
+
+void InfiniteAreaLight::create(int32_t width, int32_t height, const float* rgba) // light.cpp:34-84
+{
+    release();
+    if (width <= 0 || height <= 0 || !rgba) return;
+    m_width = width;
+    m_height = height;
+    m_texels.assign(rgba, rgba + (size_t)width * height * 4);
+    m_verticalP.resize(height);
+    m_horizontalP.resize((size_t)width * height);
+    float* vert = m_verticalP.data();
+    float* hori = m_horizontalP.data();
+    const float* p = m_texels.data();
+    float vsum = 0.0f;
+    for (uint32_t y = 0; y < (uint32_t)height; y++) {
+        float hsum = 0.0f;
+        for (uint32_t x = 0; x < (uint32_t)width; x++) {
+            uint32_t indexBase = x + y * (uint32_t)width;
+            Vector3f c(p[4 * indexBase + 0], p[4 * indexBase + 1], p[4 * indexBase + 2]);
+            float l = length(c);
+            hori[indexBase] = l;
+            hsum += l;
+        }
+        float sinPhi = std::sin(kPi * (y + 0.5f) / height);
+        vert[y] = hsum * sinPhi;
+        vsum += hsum * sinPhi;
+        float invH = 1.0f / hsum;
+        float accumH = 0.0f;
+        for (uint32_t x = 0; x < (uint32_t)width; x++) {
+            uint32_t indexBase = x + y * (uint32_t)width;
+            float ph = accumH + invH * hori[indexBase];
+            hori[indexBase] = ph;
+            accumH = ph;
+        }
+    }
+    float invV = 1.0f / vsum;
+    float accumV = 0.0f;
+    for (uint32_t y = 0; y < (uint32_t)height; y++) {
+        float pv = accumV + invV * vert[y];
+        vert[y] = pv;
+        accumV = pv;
+    }
 }
 
 void Scene::describe(prt_scene_desc& desc, DescStorage& store) const
@@ -204,6 +315,13 @@ void Scene::describe(prt_scene_desc& desc, DescStorage& store) const
     memcpy(desc.lightDir, &m_directionalLight.dir, 12);
     memcpy(desc.lightIntensity, &m_directionalLight.intensity, 12);
     desc.radius = m_radius;
+    const bool env = isLightAvailable(LightType::kInfiniteArea) && m_infiniteAreaLight.isValid();
+    desc.hasInfiniteAreaLight = env ? 1u : 0u;
+    desc.envWidth = env ? m_infiniteAreaLight.getWidth() : 0;
+    desc.envHeight = env ? m_infiniteAreaLight.getHeight() : 0;
+    desc.envTexels = env ? m_infiniteAreaLight.getTexels().data() : nullptr;
+    desc.envVerticalP = env ? m_infiniteAreaLight.getVerticalP().data() : nullptr;
+    desc.envHorizontalP = env ? m_infiniteAreaLight.getHorizontalP().data() : nullptr;
 }
 
 // ---------------------------------------------------------------- camera (camera.h:17-36)

@@ -122,6 +122,17 @@ void prt_host_scene_set_directional_light(prt_host_scene* s, const float dir[3],
     s->scene.setDirectionalLight(Vector3f(dir[0], dir[1], dir[2]), Vector3f(intensity[0], intensity[1], intensity[2]));
 }
 
+void prt_host_scene_set_env_light(prt_host_scene* s, int32_t width, int32_t height, const float* rgba)
+{
+    s->scene.setInfiniteAreaLight(width, height, rgba);
+}
+
+int prt_host_scene_load_env_light(prt_host_scene* s, const char* path)
+{
+    s->scene.setInfiniteAreaLight(path);
+    return s->scene.isLightAvailable(LightType::kInfiniteArea) ? 0 : -1;
+}
+
 const prt_scene_desc* prt_host_scene_describe(prt_host_scene* s)
 {
     s->scene.describe(s->desc, s->store);

@@ -63,6 +63,14 @@ struct DevScene {
     float lightDir[3];
     float lightIntensity[3];
     float radius;
+    // InfiniteAreaLight (light.h:28-50): float RGBA texels and the two CDF tables of light.cpp:30-84; envFirstX[y] /
+    // envFirstY = the first index >= 1 whose CDF entry differs from its predecessor (width / height when none does)
+    uint32_t hasEnv;
+    int32_t envW, envH, envFirstY;
+    const float4* envTexels;
+    const float* envV;
+    const float* envHor;
+    const int32_t* envFirstX;
 };
 
 struct DevCamera {
@@ -833,6 +841,66 @@ __device__ __forceinline__ void get_surface(const DevScene& sc, const DevHit& h,
     s.uv = Vec2{h.i * s1.w + h.j * s3.x + h.k * s3.z, h.i * s2.w + h.j * s3.y + h.k * s3.w};
     s.mat = asu(s0.w);
     s.prim = gp;
+}
+
+// ---------------------------------------------------------------------------- InfiniteAreaLight::sample, light.cpp:86-128
+// The reference scans a CDF from index 1 for the first entry that exceeds u and differs from its predecessor (:93-104,
+// :108-119).  The tables are non-decreasing (running sums of non-negative terms; upload checks it), so that index is the
+// upper bound of u found by bisection -- whose predecessor is <= u < entry, hence differs -- except when already
+// cdf[0] > u: then every entry exceeds u and the scan stops at the first one that differs from its predecessor, a
+// constant of the table (`first`).  A row of NaNs (an all-black row, :63-70) has no entry that exceeds anything,
+// under either search.  Returns `n` when the scan would run off the end.
+__device__ __forceinline__ int32_t cdf_find(const float* cdf, int32_t n, int32_t first, float u)
+{
+    int32_t lo = 1, hi = n;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid;
+        else lo = mid + 1;
+    }
+    if (lo == 1 && lo < n && cdf[0] > u) lo = first;
+    return lo;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void env_sample(const DevScene& sc, float ux, float uy, Vec3& dir, Vec3& color, Traffic& tr)
+{
+    const int32_t W = sc.envW, H = sc.envH;
+    float pdfV = 1.0f, yf = 0.0f, pdfH = 1.0f, xf = 0.0f;
+    const int32_t y = cdf_find(sc.envV, H, sc.envFirstY, uy);
+    if (y < H) {
+        float prev = sc.envV[y - 1];
+        pdfV = sc.envV[y] - prev;
+        yf = (float)y + (uy - prev) / pdfV - 1.0f;
+        // the row of the horizontal table is the CDF index y, not the texel row y-1 (:109)
+        const float* row = sc.envHor + (size_t)y * (size_t)W;
+        const int32_t x = cdf_find(row, W, sc.envFirstX[y], ux);
+        if (x < W) {
+            float prevx = row[x - 1];
+            pdfH = row[x] - prevx;
+            xf = (float)x + (ux - prevx) / pdfH - 1.0f;
+        }
+    }
+    // y == H: the reference reads one row past the table (:110); defined here as "nothing exceeds u.x" (xf = 0, pdfH = 1)
+    Vec2 uv = Vec2{xf / (float)W, yf / (float)H};
+    float k[4];
+    int32_t idx[4];
+    bilinear(k, idx, 1, uv, W, H, false); // texel indices (Texture::sample<Vector3f, float>, texture.cpp:102-139)
+    if (COUNT) tr.nTap++;
+    Vec3 c = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float4 t = sc.envTexels[idx[i]];
+        c = add3(c, scale3(k[i], mk3(t.x, t.y, t.z)));
+    }
+    c = div3s(div3s(c, pdfH * pdfV), (float)(W * H)); // :118
+    float theta = 2.0f * 3.14159265358979323846f * (uv.x + 0.5f); // :121
+    float phi = 3.14159265358979323846f * uv.y;
+    float st, ct, sp, cp;
+    prt_sincosf(theta, &st, &ct);
+    prt_sincosf(phi, &sp, &cp);
+    dir = normalize3(mk3(ct * sp, cp, st * sp)); // :125
+    color = c;
 }
 
 // material.cpp:87-96 (degamma :24-28 needs powf: see prt_powf in prt_devmath.h)

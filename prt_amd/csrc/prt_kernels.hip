@@ -172,6 +172,8 @@ struct WfArgs {
     float4* S2; // direction of the ray in flight (primary or scatter) xyz
     float4* S3; // beta.xyz
     float4* S4; // result.xyz -- belongs to the SLOT, not the path: it stays behind when the path dies or is compacted away
+    float4* S5; // environment light only: lightDir[slot].xyz      (path_tracer.cpp:125; like result, it belongs to the slot and
+    float4* S6; //                         lightIntensity[slot].xyz  keeps its last value while the packet lives)
     float4* hitA;   // t i j k
     uint2* hitB;    // primId meshId
     uint32_t* occl; // 1 = occluded
@@ -201,7 +203,7 @@ struct WfArgs {
 #define STAMP(k)
 #endif
 
-template <bool COUNT>
+template <bool COUNT, bool ENV>
 __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
 {
 #ifdef PRT_STAMP
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
     Vec3 pos = mk3(0, 0, 0), rayDir = mk3(0, 0, 0), normal = mk3(0, 0, 0), beta = mk3(1, 1, 1), result = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
     Surface props{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
     uint32_t material = 0, sflags = 0, lightSet = 0;
+    Vec3 envL = mk3(0, 0, 0), envI = mk3(0, 0, 0); // ENV: this bounce's sampled light, when the slot samples one
+    bool envSampled = false;
 
     bool needBounce = false, needEnd = false, needCamera = false;
     bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
@@ -319,8 +323,17 @@ __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
         // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
         if (sflags & SLOT_HAS_SHADOW) {
             if (A.occl[gs] == 0u) {
-                Vec3 lightDir = lightSet ? mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]) : mk3(0, 0, 0);
-                Vec3 lightInt = lightSet ? mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]) : mk3(0, 0, 0);
+                Vec3 lightDir = mk3(0, 0, 0), lightInt = mk3(0, 0, 0);
+                if (lightSet) {
+                    if (ENV) {
+                        float4 l5 = nt_load4(&A.S5[gs]), l6 = nt_load4(&A.S6[gs]);
+                        lightDir = mk3(l5.x, l5.y, l5.z);
+                        lightInt = mk3(l6.x, l6.y, l6.z);
+                    } else {
+                        lightDir = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
+                        lightInt = mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]);
+                    }
+                }
                 Vec3 lr = div3s(scale3(std_max(dot3(lightDir, normal), 0.0f), lightInt), kPi);
                 result = add3(result, mul3(beta, lr));
             }
@@ -402,11 +415,18 @@ __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
         const bool draws = active && (rtype == 0u || rtype == 1u);
         uint32_t dm = group_ballot(draws, gbase);
         uint32_t pre = 2u * __popc(dm & lowerMask), tot = 2u * __popc(dm);
-        uint32_t s = rng, r2b = 0, r1b = 0;
+        if (ENV) { // a diffuse slot draws two more for InfiniteAreaLight::sample (:164-167), after its r2, r1
+            uint32_t em = group_ballot(active && rtype == 0u, gbase);
+            pre += 2u * __popc(em & lowerMask);
+            tot += 2u * __popc(em);
+        }
+        uint32_t s = rng, r2b = 0, r1b = 0, uxb = 0, uyb = 0;
         for (uint32_t j = 0; j < tot; j++) {
             s = xorshift32(s);
             if (j == pre) r2b = s;
             if (j == pre + 1u) r1b = s;
+            if (ENV && j == pre + 2u) uxb = s;
+            if (ENV && j == pre + 3u) uyb = s;
         }
         rng = s;
         STAMP(9);
@@ -417,7 +437,12 @@ __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
             if (rtype == 0u) {
                 nextDir = dd;
                 beta = mul3(beta, sample_diffuse<COUNT>(sc, material, props.uv, tr)); // :162
-                if (sc.hasLight) { // :168-172
+                if (ENV) { // :164-167
+                    env_sample<COUNT>(sc, rng_to_float(uxb), rng_to_float(uyb), envL, envI, tr);
+                    envSampled = true;
+                    lightSet = 1u;
+                    wantLight = true;
+                } else if (sc.hasLight) { // :168-172
                     lightSet = 1u;
                     wantLight = true;
                 }
@@ -541,6 +566,10 @@ __global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
             nt_store4(&A.S1[gs], make_float4(normal.x, normal.y, normal.z, asf(sflags | (lightSet ? SLOT_LIGHT_SET : 0u))));
             nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
             nt_store4(&A.S3[gs], make_float4(beta.x, beta.y, beta.z, 0.0f));
+            if (ENV && envSampled) {
+                nt_store4(&A.S5[gs], make_float4(envL.x, envL.y, envL.z, 0.0f));
+                nt_store4(&A.S6[gs], make_float4(envI.x, envI.y, envI.z, 0.0f));
+            }
         }
         // a slot's result is stored while the slot is alive and once more in the iteration its path ends
         if (phase == PH_WAIT_BOUNCE && slot < (aliveAtEntry > alive ? aliveAtEntry : alive))
@@ -619,6 +648,7 @@ struct QueueSrc {
     uint32_t* cur;
     const float4* S0;
     const float4* S2;
+    const float4* S5; // per-slot light direction (environment light) or NULL (the scene's directional light)
     float4* hitA;
     uint2* hitB;
     uint32_t* occl;
@@ -653,7 +683,15 @@ struct QueueSrc {
             maxT = kFar; // path_tracer.cpp:270
         } else {
             float4 s0 = nt_load4(&S0[owner]);
-            Vec3 L = ((bits >> 29) & 1u) ? lightDir : mk3(0.0f, 0.0f, 0.0f);
+            Vec3 L = mk3(0.0f, 0.0f, 0.0f);
+            if ((bits >> 29) & 1u) {
+                if (S5) {
+                    float4 l5 = nt_load4(&S5[owner]);
+                    L = mk3(l5.x, l5.y, l5.z);
+                } else {
+                    L = lightDir;
+                }
+            }
             org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
             dir = mk3(-L.x, -L.y, -L.z);
             maxT = kFar - 0.0008f; // :209, 236
@@ -687,6 +725,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     src.cur = &A.qWork[MODE];
     src.S0 = A.S0;
     src.S2 = A.S2;
+    src.S5 = A.sc.hasEnv ? A.S5 : nullptr;
     src.camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     src.lightDir = mk3(A.sc.lightDir[0], A.sc.lightDir[1], A.sc.lightDir[2]);
     src.kFar = 2.0f * A.sc.radius; // path_tracer.cpp:192
@@ -950,7 +989,8 @@ static void wf_iteration(const PartRun& P, uint32_t traceBlocks)
 {
     const WfArgs& A = P.A;
     (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), P.main); // claim cursors + shard counts
-    hipLaunchKernelGGL(shade_kernel<COUNT>, dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
+    if (A.sc.hasEnv) hipLaunchKernelGGL((shade_kernel<COUNT, true>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
+    else hipLaunchKernelGGL((shade_kernel<COUNT, false>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
     (void)hipEventRecord(P.fork, P.main);
     const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
     WfArgs B = A;
@@ -1207,6 +1247,51 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     sc.radius = s->radius;
 
     int rc;
+    // InfiniteAreaLight: texels + CDF tables as they are, plus the "first index that differs from its predecessor" constants
+    // of the bisection (prt_device.h cdf_find).  The bisection needs non-decreasing tables: running sums of non-negative terms
+    // are, unless the image holds negative, infinite or NaN radiance -- refuse those.
+    sc.hasEnv = 0;
+    if (s->hasInfiniteAreaLight) {
+        const int32_t W = s->envWidth, H = s->envHeight;
+        if (W <= 0 || H <= 0 || !s->envTexels || !s->envVerticalP || !s->envHorizontalP) return fail(PRT_HIP_EINVAL, "incomplete environment light");
+        if ((int64_t)W * H > (1 << 28)) return fail(PRT_HIP_EINVAL, "environment map too large");
+        auto firstStep = [](const float* cdf, int32_t n) {
+            for (int32_t i = 1; i < n; i++) {
+                float pdf = cdf[i] - cdf[i - 1];
+                if (!(pdf == 0.0f)) return i; // light.cpp:96-98, 112-114
+            }
+            return n;
+        };
+        auto monotone = [](const float* cdf, int32_t n) {
+            for (int32_t i = 1; i < n; i++)
+                if (!(cdf[i] >= cdf[i - 1])) return false;
+            return true;
+        };
+        if (!monotone(s->envVerticalP, H)) return fail(PRT_HIP_EINVAL, "environment light: vertical CDF is not non-decreasing (negative or non-finite radiance?)");
+        std::vector<int32_t> firstX((size_t)H);
+        for (int32_t y = 0; y < H; y++) {
+            const float* row = s->envHorizontalP + (size_t)y * W;
+            const bool allNaN = row[0] != row[0]; // an all-black row: 0 * inf (light.cpp:63-70); never selected, never exceeds u
+            if (allNaN) {
+                for (int32_t x = 0; x < W; x++)
+                    if (row[x] == row[x]) return fail(PRT_HIP_EINVAL, "environment light: partly NaN CDF row");
+            } else if (!monotone(row, W)) {
+                return fail(PRT_HIP_EINVAL, "environment light: horizontal CDF is not non-decreasing (negative or non-finite radiance?)");
+            }
+            firstX[y] = firstStep(row, W);
+        }
+        std::vector<float4> tex((size_t)W * H);
+        memcpy(tex.data(), s->envTexels, tex.size() * sizeof(float4));
+        std::vector<float> vp(s->envVerticalP, s->envVerticalP + H), hp(s->envHorizontalP, s->envHorizontalP + (size_t)W * H);
+        if ((rc = upload_vec(c, tex, &sc.envTexels))) return rc;
+        if ((rc = upload_vec(c, vp, &sc.envV))) return rc;
+        if ((rc = upload_vec(c, hp, &sc.envHor))) return rc;
+        if ((rc = upload_vec(c, firstX, &sc.envFirstX))) return rc;
+        sc.envW = W;
+        sc.envH = H;
+        sc.envFirstY = firstStep(s->envVerticalP, H);
+        sc.hasEnv = 1;
+    }
     if ((rc = upload_vec(c, wnodes, &sc.wnodes))) return rc;
     if ((rc = upload_vec(c, tris, &sc.tris))) return rc;
     if ((rc = upload_vec(c, shade, &sc.shade))) return rc;
@@ -1257,7 +1342,7 @@ static int persistent_blocks(prt_hip_ctx* c)
 }
 
 // Carves the wavefront state of the pipelines of a pass (groups[k] pixel groups each) out of one allocation.
-static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, WfArgs* A)
+static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env, WfArgs* A)
 {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     auto entries = [](size_t slots) { return slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK; };
@@ -1265,7 +1350,7 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, WfArgs* 
     for (int k = 0; k < parts; k++) {
         const size_t g = groups[k], slots = g * 8;
         need += 3 * al(g * sizeof(uint32_t)) + al(g * sizeof(float4));
-        need += 5 * al(slots * sizeof(float4));                                                        // S0..S4
+        need += (env ? 7 : 5) * al(slots * sizeof(float4));                                            // S0..S4 (S5, S6)
         need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t)); // hits, occlusion
         need += Q_COUNT * al(entries(slots) * sizeof(uint32_t));
     }
@@ -1289,6 +1374,8 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, WfArgs* 
         A[k].S2 = (float4*)take(slots * sizeof(float4));
         A[k].S3 = (float4*)take(slots * sizeof(float4));
         A[k].S4 = (float4*)take(slots * sizeof(float4));
+        A[k].S5 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
+        A[k].S6 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
         A[k].hitA = (float4*)take(slots * sizeof(float4));
         A[k].hitB = (uint2*)take(slots * sizeof(uint2));
         A[k].occl = (uint32_t*)take(slots * sizeof(uint32_t));
@@ -1372,11 +1459,12 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         uint32_t maxGroups[PRT_PARTS];
         WfArgs L[PRT_PARTS];
         for (int k = 0; k < parts; k++) maxGroups[k] = (uint32_t)(((passTiles - k + parts - 1) / parts) * tile2);
-        if ((rc = wf_layout(c, maxGroups, parts, L))) return rc;
+        if ((rc = wf_layout(c, maxGroups, parts, c->sc.hasEnv != 0, L))) return rc;
         for (int k = 0; k < parts; k++) {
             P[k].A = A;
             P[k].A.gRng = L[k].gRng; P[k].A.gInfo = L[k].gInfo; P[k].A.gPixel = L[k].gPixel; P[k].A.gColor = L[k].gColor;
             P[k].A.S0 = L[k].S0; P[k].A.S1 = L[k].S1; P[k].A.S2 = L[k].S2; P[k].A.S3 = L[k].S3; P[k].A.S4 = L[k].S4;
+            P[k].A.S5 = L[k].S5; P[k].A.S6 = L[k].S6;
             P[k].A.hitA = L[k].hitA; P[k].A.hitB = L[k].hitB; P[k].A.occl = L[k].occl;
             for (int q = 0; q < Q_COUNT; q++) P[k].A.qE[q] = L[k].qE[q];
             P[k].A.qWork = c->work + (size_t)k * PRT_WORK_WORDS;

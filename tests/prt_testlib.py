@@ -536,7 +536,7 @@ def scene_desc_from_product(scene, camera, exposure=1.0):
     light = (a["light_dir"], a["light_intensity"]) if a["has_light"] else None
     # Camera::create's ARGUMENTS (camera.desc.dir is already normalised; the basis depends on the raw direction)
     d = SceneDesc(meshes, camera.pos_arg, camera.dir_arg, camera.width, camera.height, light=light, textures=a["textures"],
-                  exposure=exposure)
+                  exposure=exposure, env=a["env"])
     d.product_arrays = a
     return d
 

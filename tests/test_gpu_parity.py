@@ -394,3 +394,40 @@ def test_large_scene_4k_two_passes_matches_oracle_tiles(tracer):
     for (x0, y0) in ((0, 0), (1904, 1072), (3824, 2144), (640, 1600)):
         ref, _ = s.trace_block(x0, y0, x0 + 15, y0 + 15, 8, max_depth=12)
         assert_bits_equal(img[y0:y0 + 16, x0:x0 + 16], ref, f"4K tile at {(x0, y0)}")
+
+
+def test_infinite_area_light_matches_reference_and_oracle(tracer):
+    """environment light sampled in the kernels (bisection instead of the reference's linear CDF scan, the two
+    extra draws per diffuse bounce, per-slot light direction for the occlusion rays).  Cornell box lit by a seeded float
+    map: the 64x64 crop equals the compiled reference's output bit for bit (tests/golden/env_light.npz); a map with
+    all-black rows/columns (zero-pdf entries, NaN CDF rows) and the specular teapot equals the oracle, counters included."""
+    z = np.load(os.path.join(G, "env_light.npz"))
+    scene, camera, exposure = prt_amd.setup_cornell_box(96, 96)
+    scene.set_infinite_area_light(T.sky_env(64, 32))
+    upload(tracer, scene, camera)
+    x0, y0, x1, y1 = (int(v) for v in z["rect"])
+    rgb = tracer.trace_block(x0, y0, x1, y1, 16)
+    assert_bits_equal(rgb, z["rgb"], "env-lit Cornell crop vs compiled reference")
+    st = tracer.last_stats
+    assert st["raysTraced"] == int(z["rays"][0]) and st["occludedTraced"] == int(z["rays"][1])
+
+    scene, camera, exposure = prt_amd.setup_cornell_box(128, 128, teapot_mesh=T.teapot_product_mesh())
+    scene.set_infinite_area_light(T.sky_env(48, 24, black_rows=True))
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    rgb = tracer.render(16, max_depth=8, count_traffic=True)
+    st = tracer.last_stats
+    s = T.OracleScene(desc)
+    ref, ost = s.render(16, max_depth=8)
+    assert ost["occludedTraced"] > 0
+    assert_bits_equal(rgb, ref, "env-lit Cornell + teapot vs oracle")
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    # a directional light set afterwards switches the environment light off (scene.h:30-35)
+    scene.set_directional_light((0.2, 1.0, 0.2), (3.0, 3.0, 3.0))
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    assert desc.env is None
+    rgb = tracer.render(8, max_depth=4)
+    ref, _ = T.OracleScene(desc).render(8, max_depth=4)
+    assert_bits_equal(rgb, ref, "directional light after environment light")

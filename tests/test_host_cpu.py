@@ -136,7 +136,8 @@ def test_bvh_build_matches_oracle_on_random_soups(L, n, seed):
 
 
 def test_devmath_matches_libm_on_every_path_argument(tmp_path):
-    """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce; powf(x, 2.2): every float in [2^-24, 1]."""
+    """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce and every float in [-0.5, 10] (environment light angles);
+    powf(x, 2.2): every float in [2^-24, 1]."""
     src = tmp_path / "dm.c"
     src.write_text(r'''
 #include <stdio.h>
@@ -147,6 +148,10 @@ int main(){ const float kPi = 3.14159265358979323846f; long bad=0;
   for(uint32_t k=0;k<(1u<<23);k++){ uint32_t b=k|0x3f800000u; float f; memcpy(&f,&b,4); float theta=2.0f*kPi*(f-1.0f);
     float s,c; prt_sincosf(theta,&s,&c); float gs=sinf(theta), gc=cosf(theta);
     if(memcmp(&s,&gs,4)||memcmp(&c,&gc,4)) bad++; }
+  /* environment light (light.cpp:121-125): theta = 2*pi*(u+0.5), phi = pi*v with u, v a little below 0 up to 1: every float in [-0.5, 0) and [0, 10] */
+  for(int neg=0;neg<2;neg++){ float top=neg?0.5f:10.0f; uint32_t hi; memcpy(&hi,&top,4);
+    for(uint32_t b=0;b<=hi;b++){ uint32_t bb=b|(neg?0x80000000u:0u); float y; memcpy(&y,&bb,4);
+      float s,c; prt_sincosf(y,&s,&c); float gs=sinf(y), gc=cosf(y); if(memcmp(&s,&gs,4)||memcmp(&c,&gc,4)) bad++; } }
   for(uint32_t b=0x33800000u;b<=0x3f800000u;b++){ float x; memcpy(&x,&b,4); float m=prt_powf_2p2(x), g=powf(x,2.2f); if(memcmp(&m,&g,4)) bad++; }
   float z=0.0f, m=prt_powf_2p2(z), g=powf(z,2.2f); if(memcmp(&m,&g,4)) bad++;
   printf("%%ld\n", bad); return 0; }
@@ -154,3 +159,34 @@ int main(){ const float kPi = 3.14159265358979323846f; long bad=0;
     exe = tmp_path / "dm"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", str(src), "-o", str(exe), "-lm"])
     assert subprocess.check_output([str(exe)]).decode().strip() == "0"
+
+
+def test_infinite_area_light_tables_match_oracle(L, tmp_path):
+    """Scene::setInfiniteAreaLight -> InfiniteAreaLight::create (light.cpp:30-84) on the host: the CDF tables handed to the
+    kernels equal the oracle's (which equal the compiled reference's, tests/golden/env_light.npz), from memory and from a PFM."""
+    env = T.sky_env(48, 24, black_rows=True)
+    scene, camera, exposure = prt_amd.setup_cornell_box(64, 64)
+    scene.set_infinite_area_light(env)
+    a = scene.arrays()
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    s = T.OracleScene(desc)
+    vp, hp = s.env_tables()
+    assert np.array_equal(a["env"].view(np.uint32), env.view(np.uint32))
+    assert np.array_equal(a["env_vertical"].view(np.uint32), vp.view(np.uint32))
+    assert np.array_equal(a["env_horizontal"].view(np.uint32), hp.view(np.uint32))
+    z = np.load(os.path.join(T.GOLDEN, "env_light.npz"))
+    assert np.array_equal(a["env_vertical"].view(np.uint32), z["black_rows_vertical"].view(np.uint32))
+    # the same map through a little-endian PFM (rows bottom to top)
+    p = tmp_path / "env.pfm"
+    with open(p, "wb") as f:
+        f.write(b"PF\n48 24\n-1.0\n")
+        f.write(np.ascontiguousarray(env[::-1, :, :3], dtype="<f4").tobytes())
+    scene2, _, _ = prt_amd.setup_cornell_box(64, 64)
+    scene2.set_infinite_area_light(str(p))
+    b = scene2.arrays()
+    assert np.array_equal(b["env"].view(np.uint32), env.view(np.uint32))
+    assert np.array_equal(b["env_horizontal"].view(np.uint32), hp.view(np.uint32))
+    scene3, _, _ = prt_amd.setup_cornell_box(64, 64)
+    with pytest.raises(prt_amd.PrtError):
+        scene3.set_infinite_area_light(str(tmp_path / "missing.pfm"))
+    assert scene3.arrays()["env"] is None
