@@ -20,7 +20,10 @@ HEADERS = ["prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc
 
 # -ffp-contract=off: the reference's object code has no FMA, and results must match it bit for bit.
 # No fast-math; HIP's default correctly-rounded f32 divide/sqrt is kept.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+# -fno-slp-vectorize: the trace kernels are VALU-issue-bound (PMC: 75 % busy at 24 of 64 lanes per instruction); the SLP
+# vectoriser's v_pk_* pairs cost more v_mov shuffling than they save (C3 frame 591 -> 551 ms).  The node step keeps its
+# hand-packed (lo, hi) slab pairs, whose operands come out of the loads already paired.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

@@ -125,6 +125,9 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
+#ifndef PRT_TRACE_BPC
+#define PRT_TRACE_BPC 4 // persistent blocks per CU and trace kernel
+#endif
 #ifndef PRT_PARTS
 #define PRT_PARTS 2 // independent pipelines a pass is dealt to
 #endif
@@ -1336,7 +1339,7 @@ static int persistent_blocks(prt_hip_ctx* c)
         // Up to eight trace kernels are in flight (two pipelines x four queues) and a CU holds 8 blocks of 256 threads: 4 per
         // kernel and CU leaves room for the other pipeline's kernels (measured on C3: 1: 933 ms, 2: 627, 3: 594, 4: 588,
         // 5: 599, 6: 608, 8: 631)
-        c->blocksPerCU = std::min(nb, 4);
+        c->blocksPerCU = std::min(nb, PRT_TRACE_BPC);
     }
     return c->computeUnits * c->blocksPerCU;
 }
