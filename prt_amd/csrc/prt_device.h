@@ -372,9 +372,13 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, V
 
 // Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper
 // ones in a per-thread global spill area.  `t` (the box entry distance) is only stored by the packet traversal.
+// LDS-typed pointers: through a generic pointer the pop `lds[e] or spill[e]` compiles to one flat load, which goes down the
+// texture path the node and triangle fetches already saturate
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) float lds_f32;
 struct Stack {
-    uint32_t* ldsRef; // &refs[threadIdx.x]
-    float* ldsT;      // &ts[threadIdx.x]
+    lds_u32* ldsRef; // &refs[threadIdx.x]
+    lds_f32* ldsT;   // &ts[threadIdx.x]
     uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
     uint32_t spillStride;
     __device__ __forceinline__ void put(int e, uint32_t ref) const
@@ -384,7 +388,9 @@ struct Stack {
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
-        return (e < PRT_STACK_LDS) ? ldsRef[e * PRT_BLOCK] : spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride];
+        uint32_t v = ldsRef[(e & (PRT_STACK_LDS - 1)) * PRT_BLOCK];
+        if (e >= PRT_STACK_LDS) v = spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride];
+        return v;
     }
     __device__ __forceinline__ void putT(int e, uint32_t ref, float t) const
     {
@@ -398,7 +404,9 @@ struct Stack {
     }
     __device__ __forceinline__ float getT(int e) const
     {
-        return (e < PRT_STACK_LDS) ? ldsT[e * PRT_BLOCK] : asf(spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride]);
+        float v = ldsT[(e & (PRT_STACK_LDS - 1)) * PRT_BLOCK];
+        if (e >= PRT_STACK_LDS) v = asf(spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride]);
+        return v;
     }
 };
 

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? PRT_STACK_LDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const Stack st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     QueueSrc<MODE> src;
     src.qe = A.qE[MODE];
     src.n = 0;
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
     __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const Stack st{&ldsRef[tid], &ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const Stack st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     ArraySrc src{&A, MODE};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
