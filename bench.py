@@ -42,6 +42,13 @@ WORKLOADS = {
     "c2_bunny_standin": ("setup_bunny_standin", dict(tris=69451, seed=1), 1024, 1024, 64, 14,
                          "BASELINE config 2: Cornell box + bunny-class stand-in (69k tris) + directional light, 1024x1024, 64 spp"),
     "c1_cornell_teapot": ("setup_cornell_box", dict(), 512, 512, 16, 4, "BASELINE config 1: Cornell box (teapot needs the reference's asset), 512x512, 16 spp, depth 4"),
+    # the two 8-GPU configurations of BASELINE.json (parity-test cases; selectable, never the default)
+    "c4_sanmiguel_standin": ("setup_atrium_standin", dict(tris=2500000, seed=4), 1920, 1080, 256, 14,
+                             "BASELINE config 4: San-Miguel-class stand-in (2.5 M tris, alpha-masked foliage cards, bump map, directional light), "
+                             "1920x1080, 256 spp"),
+    "c5_zeroday_standin": ("setup_atrium_standin", dict(tris=5000000, seed=5, emissive_fraction=0.1, light=False), 3840, 2160, 1024, 12,
+                           "BASELINE config 5: Zero-Day-class stand-in (5 M tris, 10 % emissive triangles, no directional light), "
+                           "3840x2160, 1024 spp, depth 12"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 

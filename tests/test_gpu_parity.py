@@ -431,3 +431,38 @@ def test_infinite_area_light_matches_reference_and_oracle(tracer):
     rgb = tracer.render(8, max_depth=4)
     ref, _ = T.OracleScene(desc).render(8, max_depth=4)
     assert_bits_equal(rgb, ref, "directional light after environment light")
+
+
+def test_nan_rays_are_answered_without_the_full_walk(tracer):
+    """A NaN shading normal (degenerate vertex normals in real assets) gives NaN scatter rays.  Under the reference's
+    min/max semantics such a ray passes every box test and misses every triangle: the timed build answers "miss" at once,
+    the counting build walks the whole tree like the reference; both must give the oracle's image, the latter its counters."""
+    m = T.oracle_vertex_normals(T.load_cornell_mesh())
+    n = m.normals.copy()
+    floor = np.where(np.abs(m.positions[:, 1]) < 1e-6)[0]
+    assert len(floor) >= 4
+    n[floor[:2]] = np.nan  # two floor vertices: every hit on their triangles interpolates a NaN normal
+    pm = prt_amd.Mesh.from_arrays(m.indices, m.positions, m.prim_material, m.materials.view(prt_amd.MATERIAL_DTYPE), normals=n)
+    pm.calculate_bounds()
+    scene = prt_amd.Scene()
+    scene.add(pm)
+    scene.set_directional_light((0.2, 1.0, 0.2), (3.0, 3.0, 3.0))
+    camera = prt_amd.Camera().create((0, 0.965, 2.6), (0, 0, -1.0), 96, 96)
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, 1.0)
+    s = T.OracleScene(desc)
+    ref, ost = s.render(16, max_depth=8)
+    assert np.isnan(ref).any(), "the scene must actually produce NaN paths"
+    nan = np.isnan(ref)  # a NaN's sign and payload differ between SSE (0xffc00000) and the GPU (0x7fc00000): compare "is NaN"
+
+    def same(img, what):
+        assert np.array_equal(np.isnan(img), nan), what
+        assert_bits_equal(img[~nan], ref[~nan], what)
+
+    same(tracer.render(16, max_depth=8), "NaN-normal scene, timed build")
+    st = tracer.last_stats
+    assert st["raysTraced"] == ost["raysTraced"] and st["occludedTraced"] == ost["occludedTraced"]
+    same(tracer.render(16, max_depth=8, count_traffic=True), "NaN-normal scene, counting build")
+    st = tracer.last_stats
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
