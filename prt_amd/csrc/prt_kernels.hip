@@ -128,6 +128,9 @@ enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #ifndef PRT_TRACE_BPC
 #define PRT_TRACE_BPC 4 // persistent blocks per CU and trace kernel
 #endif
+#ifndef PRT_SIDE_STREAMS
+#define PRT_SIDE_STREAMS 1 // side streams per pipeline for the three smaller trace kernels (1 or 3)
+#endif
 #ifndef PRT_PARTS
 #define PRT_PARTS 2 // independent pipelines a pass is dealt to
 #endif
@@ -949,8 +952,8 @@ struct prt_hip_ctx {
     // trace) and a side stream (the other three trace kernels): stream, aux[0] | aux[1], aux[2] | ...  Two pipelines = four
     // streams = the four hardware queues a HIP process gets by default (measured on C3, whole frame / one rank's share of
     // 8: 2 pipelines 588 / 102 ms; 3: 590-660 / 110-138; 4: 595-657 / 106-135 depending on GPU_MAX_HW_QUEUES).
-    hipStream_t aux[2 * PRT_PARTS - 1] = {};
-    hipEvent_t evFork[PRT_PARTS] = {}, evJoin[PRT_PARTS] = {};
+    hipStream_t aux[(1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1] = {};
+    hipEvent_t evFork[PRT_PARTS] = {}, evJoin[PRT_PARTS * PRT_SIDE_STREAMS] = {};
     hipEvent_t evStart = nullptr, evDone[PRT_PARTS] = {}; // pipelines 1.. against the main stream, per pass
     hipEvent_t evIn = nullptr, evOut = nullptr; // order the pipeline against a caller's stream
     void* wfBuffer = nullptr; // wavefront state + queues of one pass
@@ -978,8 +981,8 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
 struct PartRun {
     WfArgs A;
     uint32_t shadeBlocks = 0;
-    hipStream_t main = nullptr, side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t main = nullptr, side[PRT_SIDE_STREAMS] = {};
+    hipEvent_t fork = nullptr, join[PRT_SIDE_STREAMS] = {};
     int index = 0;
 };
 
@@ -997,16 +1000,17 @@ static void wf_iteration(const PartRun& P, uint32_t traceBlocks)
     (void)hipEventRecord(P.fork, P.main);
     const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
     WfArgs B = A;
-    (void)hipStreamWaitEvent(P.side, P.fork, 0);
+    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipStreamWaitEvent(P.side[k], P.fork, 0);
+    // the three smaller kernels go round the side streams (1: one after the other, 3: each on its own)
     B.spill = A.spill + 1 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[0 % PRT_SIDE_STREAMS], B);
     B.spill = A.spill + 2 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
+    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[1 % PRT_SIDE_STREAMS], B);
     B.spill = A.spill + 3 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side, B);
-    (void)hipEventRecord(P.join, P.side);
+    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[2 % PRT_SIDE_STREAMS], B);
+    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipEventRecord(P.join[k], P.side[k]);
     hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.main, A);
-    (void)hipStreamWaitEvent(P.main, P.join, 0);
+    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipStreamWaitEvent(P.main, P.join[k], 0);
 }
 
 extern "C" {
@@ -1039,15 +1043,13 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < PRT_PARTS; k++) {
-        HIP_TRY(hipEventCreateWithFlags(&c->evFork[k], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
-    }
+    for (int k = 0; k < PRT_PARTS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evFork[k], hipEventDisableTiming));
+    for (int k = 0; k < PRT_PARTS * PRT_SIDE_STREAMS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
     for (int k = 0; k < PRT_PARTS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
-    for (int k = 0; k < 2 * PRT_PARTS - 1; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
+    for (int k = 0; k < (1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
     HIP_TRY(hipMalloc(&c->work, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMemset(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
@@ -1078,12 +1080,12 @@ void prt_hip_destroy(prt_hip_ctx* c)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (int k = 0; k < 2 * PRT_PARTS - 1; k++)
+    for (int k = 0; k < (1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1; k++)
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
-    for (int k = 0; k < PRT_PARTS; k++) {
+    for (int k = 0; k < PRT_PARTS; k++)
         if (c->evFork[k]) (void)hipEventDestroy(c->evFork[k]);
+    for (int k = 0; k < PRT_PARTS * PRT_SIDE_STREAMS; k++)
         if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
-    }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     for (int k = 0; k < PRT_PARTS; k++)
         if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]);
@@ -1474,10 +1476,13 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
             P[k].A.spill = c->spill + (size_t)k * 4 * spillWords;
             P[k].A.partIndex = (uint32_t)k;
             P[k].A.partCount = (uint32_t)parts;
-            P[k].main = (k == 0) ? s : c->aux[2 * k - 1];
-            P[k].side = c->aux[2 * k];
+            // streams of pipeline k: aux[k*(1+S) - 1] (main; pipeline 0 uses the context's stream) and the S after it
+            P[k].main = (k == 0) ? s : c->aux[k * (1 + PRT_SIDE_STREAMS) - 1];
+            for (int j = 0; j < PRT_SIDE_STREAMS; j++) {
+                P[k].side[j] = c->aux[k * (1 + PRT_SIDE_STREAMS) + j];
+                P[k].join[j] = c->evJoin[k * PRT_SIDE_STREAMS + j];
+            }
             P[k].fork = c->evFork[k];
-            P[k].join = c->evJoin[k];
             P[k].index = k;
         }
     }
