@@ -160,6 +160,11 @@ int prt_hip_render(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint
 /* copies the rectangle (inclusive) of the context's framebuffer into a host image of the camera's size */
 int prt_hip_download(prt_hip_ctx* ctx, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 float* prt_hip_framebuffer(prt_hip_ctx* ctx); /* device pointer, width*height*3 floats */
+/* Single-process multi-GPU hosts: n contexts, context i having rendered its share of the SAME rectangle with
+ * params.rank = i, params.nranks = n into its own framebuffer (d_rgb = NULL).  Assembles the image in rgb_host (camera-sized):
+ * every pixel of the rectangle is taken from the context that owns its tile.  (One process per GPU -- the arrangement bench.py
+ * uses -- gathers with one RCCL reduce instead: prt_amd.gather_image.) */
+int prt_hip_gather(prt_hip_ctx* const* ctxs, int n, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 int prt_hip_get_stats(prt_hip_ctx* ctx, prt_hip_stats* stats);
 
 /* ---- row-level entry points (parity tests of the traversal rows; host pointers) ----

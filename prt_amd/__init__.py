@@ -103,7 +103,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 # every symbol include/prt_hip.h and include/prt_host.h declare
 EXPORTS = [
     "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
-    "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_download", "prt_hip_framebuffer",
+    "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
     "prt_hip_get_stats", "prt_hip_trace_rays", "prt_hip_test_leaf", "prt_hip_test_sincos", "prt_hip_test_powf",
     "prt_hip_test_camera",
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
@@ -140,6 +140,7 @@ def lib():
     L.prt_hip_set_camera.argtypes = [vp, C.POINTER(CameraDesc)]
     L.prt_hip_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RenderParams), vp, vp]
     L.prt_hip_download.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.prt_hip_gather.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.prt_hip_framebuffer.restype = vp
     L.prt_hip_framebuffer.argtypes = [vp]
     L.prt_hip_get_stats.argtypes = [vp, C.POINTER(HipStats)]
@@ -501,6 +502,16 @@ def owned_pixel_mask(width, height, rank, nranks, tile=16):
     ty, tx = np.meshgrid(np.arange(height) // tile, np.arange(width) // tile, indexing="ij")
     tiles_x = (width + tile - 1) // tile
     return ((ty * tiles_x + tx) % nranks) == rank
+
+
+def gather_contexts(tracers, x0, y0, x1, y1):
+    """prt_hip_gather: one process driving several contexts (tracer i rendered the rectangle with rank=i, nranks=len(tracers)
+    into its own framebuffer); returns the assembled (H, W, 3) image."""
+    cam = tracers[0]._camera
+    img = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+    arr = (C.c_void_p * len(tracers))(*[t._ctx for t in tracers])
+    _check(lib().prt_hip_gather(arr, len(tracers), img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_gather")
+    return img
 
 
 def gather_image(framebuffer, dst=0):

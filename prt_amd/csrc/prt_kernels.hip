@@ -961,6 +961,7 @@ struct prt_hip_ctx {
     uint32_t wfGroups = 0;
     uint32_t* spill = nullptr;
     uint32_t spillThreads = 0;
+    uint32_t lastRank = 0, lastNranks = 0, lastTile = 0; // of the last render (prt_hip_gather)
     int blocksPerCU = 0;
     bool timed = false;
 };
@@ -1531,6 +1532,9 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("wavefront launch: ") + hipGetErrorString(le));
     HIP_TRY(hipEventRecord(ev1, s));
+    c->lastRank = p->rank;
+    c->lastNranks = p->nranks;
+    c->lastTile = p->tileSize;
     if (caller) {
         HIP_TRY(hipEventRecord(c->evOut, s));
         HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
@@ -1553,6 +1557,40 @@ int prt_hip_download(prt_hip_ctx* c, float* rgb_host, uint32_t x0, uint32_t y0, 
     size_t off = ((size_t)y0 * W + x0) * 3;
     HIP_TRY(hipMemcpy2D(rgb_host + off, (size_t)W * 3 * sizeof(float), c->fb + off, (size_t)W * 3 * sizeof(float), rowBytes,
                         y1 - y0 + 1, hipMemcpyDeviceToHost));
+    return PRT_HIP_OK;
+}
+
+int prt_hip_gather(prt_hip_ctx* const* ctxs, int n, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
+{
+    if (!ctxs || n <= 0 || !rgb_host) return fail(PRT_HIP_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !ctxs[i]->fb) return fail(PRT_HIP_ESTATE, "a context has nothing rendered into its framebuffer");
+        if (ctxs[i]->lastNranks != (uint32_t)n || ctxs[i]->lastRank != (uint32_t)i)
+            return fail(PRT_HIP_ESTATE, "context i must have rendered with rank = i, nranks = n");
+        if (ctxs[i]->cam.width != ctxs[0]->cam.width || ctxs[i]->cam.height != ctxs[0]->cam.height || ctxs[i]->lastTile != ctxs[0]->lastTile)
+            return fail(PRT_HIP_ESTATE, "contexts disagree on image size or tile size");
+    }
+    const uint32_t W = ctxs[0]->cam.width, H = ctxs[0]->cam.height, T = ctxs[0]->lastTile;
+    if (x1 < x0 || y1 < y0 || x1 >= W || y1 >= H) return fail(PRT_HIP_EINVAL, "pixel rectangle outside the image");
+    const uint32_t tilesX = (W + T - 1) / T;
+    const size_t rowFloats = (size_t)(x1 - x0 + 1) * 3;
+    std::vector<float> part((size_t)(y1 - y0 + 1) * rowFloats);
+    for (int i = 0; i < n; i++) {
+        prt_hip_ctx* c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy2D(part.data(), rowFloats * sizeof(float), c->fb + ((size_t)y0 * W + x0) * 3, (size_t)W * 3 * sizeof(float),
+                            rowFloats * sizeof(float), y1 - y0 + 1, hipMemcpyDeviceToHost));
+        for (uint32_t y = y0; y <= y1; y++) {
+            const float* src = &part[(size_t)(y - y0) * rowFloats];
+            float* dst = rgb_host + ((size_t)y * W + x0) * 3;
+            for (uint32_t x = x0; x <= x1;) {
+                const uint32_t tile = (y / T) * tilesX + x / T, xe = std::min<uint32_t>(x1, (x / T + 1) * T - 1);
+                if (tile % (uint32_t)n == (uint32_t)i) memcpy(dst + (size_t)(x - x0) * 3, src + (size_t)(x - x0) * 3, (size_t)(xe - x + 1) * 3 * sizeof(float));
+                x = xe + 1;
+            }
+        }
+    }
     return PRT_HIP_OK;
 }
 

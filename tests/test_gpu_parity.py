@@ -466,3 +466,27 @@ def test_nan_rays_are_answered_without_the_full_walk(tracer):
     st = tracer.last_stats
     for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
         assert st[k] == ost[k], (k, st[k], ost[k])
+
+
+def test_single_process_gather_of_several_contexts(tracer, c1):
+    """prt_hip_gather (the single-process arrangement): three contexts render rank 0/1/2 of 3 of a ragged
+    rectangle; the assembled image equals one context rendering it alone, bit for bit.  (Three contexts on one device
+    here; on a multi-GPU host each would sit on its own.)"""
+    scene, camera, desc = c1
+    upload(tracer, scene, camera)
+    rect = (37, 21, 300, 210)
+    whole = tracer.trace_block(*rect, 8, max_depth=4)
+    others = [prt_amd.PathTracer(device=0, max_depth=4, seed=12345) for _ in range(3)]
+    try:
+        for i, t in enumerate(others):
+            t.upload_scene(scene)
+            t.set_camera(camera)
+            t.render_async(*rect, 8, rank=i, nranks=3)
+        img = prt_amd.gather_contexts(others, *rect)
+        x0, y0, x1, y1 = rect
+        assert_bits_equal(img[y0:y1 + 1, x0:x1 + 1], whole, "gathered image")
+        with pytest.raises(prt_amd.PrtError):
+            prt_amd.gather_contexts(others[:2], *rect)  # rendered as 3 ranks, gathered as 2
+    finally:
+        for t in others:
+            t.close()
