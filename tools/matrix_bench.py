@@ -1,4 +1,5 @@
-"""C3 kernel time per (library variant, env setting, rank share).  Diagnostic only."""
+"""C3 kernel time per library variant in prt_amd/lib/var/ (tools/build_variants.py) and GPU_MAX_HW_QUEUES setting, for the whole
+frame and for one rank's share of 8.  usage: matrix_bench.py 4,16   Diagnostic only."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "--child":
@@ -22,6 +23,5 @@ else:
     var = os.path.join(root, "prt_amd", "lib", "var")
     for f in sorted(os.listdir(var)):
         for q in sys.argv[1].split(","):
-            for b in sys.argv[2].split(","):
-                env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = q; env["PRT_TRACE_BPC"] = b
-                subprocess.call([sys.executable, os.path.abspath(__file__), "--child", os.path.join(var, f), f"{f} hwq={q} bpc={b}"], env=env)
+            env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = q
+            subprocess.call([sys.executable, os.path.abspath(__file__), "--child", os.path.join(var, f), f"{f} hwq={q}"], env=env)
