@@ -8,7 +8,8 @@
  * Each function cites the reference file:line (under /root/reference/src) that it follows.
  * Parity status: pinned against the compiled reference (oracle/_ref, built from the reference's
  * own sources by oracle/Makefile) for RNG, camera packets, BVH build/flatten, the four
- * traversals, triangle and box tests and the bounce loop; the functions the reference keeps in
+ * traversals, triangle and box tests, the bounce loop and the infinite-area light (create + sample);
+ * the functions the reference keeps in
  * mesh.cpp / material.cpp / texture.cpp (surface fetch, bump/diffuse/alpha sampling) cannot be
  * compiled here (they include un-vendored third-party headers) and are pinned by restatement
  * only -- see DESIGN.md "Oracle".
