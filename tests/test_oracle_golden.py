@@ -198,3 +198,17 @@ def test_env_light_matches_reference():
     rgb, st = s.render_rect((x0, y0, x1, y1), 16, max_depth=14)
     assert_bits_equal(rgb, z["rgb"], "env-lit Cornell crop")
     assert st["raysTraced"] == int(z["rays"][0]) and st["occludedTraced"] == int(z["rays"][1])
+
+
+def test_reference_own_test_program_passes():
+    """tests/tests.cpp of the reference, compiled from its own sources by oracle/Makefile (vecmath lane operations, the
+    `t == 1.0f` triangle that is also leaf fixture 0, the thread pool): a failed assertion prints and traps."""
+    exe = os.path.join(T.ORACLE_DIR, "_ref", "ref_tests")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_tests is only built where /root/reference exists")
+    import subprocess
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "assertion failed" not in p.stdout
+    for name in ("test_vecmath()", "test_triangle_intersection()", "test_thread_pool()"):
+        assert name in p.stdout
