@@ -524,3 +524,25 @@ def test_full_size_c3_properties(tracer):
     for (x0, y0) in ((952, 532), (64, 1000), (1800, 40), (1904, 1064)):
         ref, _ = s.trace_block(x0, y0, x0 + 15, y0 + 15, spp, max_depth=depth)
         assert_bits_equal(a[y0:y0 + 16, x0:x0 + 16], ref, f"tile at {(x0, y0)}")
+
+
+@pytest.mark.parametrize("spp,max_depth,seed,tile", [(24, 14, 12345, 16), (8, 1, 777, 16), (4, 14, 12345, 16), (16, 2, 1, 8), (16, 6, 99, 32),
+                                                      (40, 0, 5, 16)])
+def test_parameter_corners_match_oracle(tracer, spp, max_depth, seed, tile):
+    """Sample counts that are not a multiple of 8 (the divisor stays `samples`, path_tracer.cpp:28,65; fewer than 8 renders
+    black), depth caps 0/1/2, other seeds, other tile sizes (a launch-partition parameter: it must not change a pixel)."""
+    scene, camera, exposure = prt_amd.setup_bunny_standin(96, 80, tris=5000)
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    t = prt_amd.PathTracer(device=0, max_depth=max_depth, seed=seed)
+    try:
+        t.upload_scene(scene)
+        t.set_camera(camera)
+        rgb = t.render(spp, exposure=exposure, tile=tile, count_traffic=True)
+        st = t.last_stats
+    finally:
+        t.close()
+    ref, ost = T.OracleScene(desc).render(spp, max_depth=max_depth, seed=seed)
+    assert_bits_equal(rgb, ref, f"spp {spp} depth {max_depth} seed {seed} tile {tile}")
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
