@@ -1412,6 +1412,11 @@ static v3 diffuse_dir(v3 normal, float r2, float r1) /* :143-153 / :176-184 */
     return add3(add3(scale3(r2sq * cosf(theta), binormal), scale3(r2sq * sinf(theta), tangent)), scale3(1 - r2, normal));
 }
 
+/* Russian roulette starts when depth > this; 4 is the reference's literal (path_tracer.cpp:258).  A parameter of the
+ * product (prt_render_params.rrDepth), so the checker has it too. */
+static uint32_t g_rr_depth = 4;
+void orc_set_rr_depth(uint32_t d) { g_rr_depth = d; }
+
 static v3 compute_radiance(const orc_scene* scene, uint32_t* rng, const orc_hit hitPacket[LANES], const float org[LANES][3],
                            const float dirs[LANES][3], uint32_t maxDepth, uint32_t rrDepth, orc_stats* st)
 {
@@ -1560,7 +1565,7 @@ static void trace_pixel(const orc_scene* scene, const orc_camera* cam, uint32_t 
         camera_packet(cam, &rng, x, y, org, dir, avgDir, st);
         orc_hit hits[LANES];
         orc_intersect_packet(scene, org, dir, avgDir, 100000.0f, hits, st);
-        color = add3(color, compute_radiance(scene, &rng, hits, org, dir, maxDepth, 4, st));
+        color = add3(color, compute_radiance(scene, &rng, hits, org, dir, maxDepth, g_rr_depth, st));
     }
     color = div3(color, v3s((float)samples));
     v3 c = scale3(exposure, color); /* image.cpp:45 */

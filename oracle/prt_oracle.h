@@ -154,6 +154,7 @@ void orc_render(const orc_scene*, const orc_camera*, uint32_t samples, uint32_t 
 void orc_render_rect(const orc_scene*, const orc_camera*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t samples,
                      uint32_t maxDepth, uint32_t seed, float exposure, int threads, float* rgb, orc_stats* st);
 int orc_max_threads(void);
+void orc_set_rr_depth(uint32_t rrDepth); /* default 4 = the reference (path_tracer.cpp:258) */
 
 /* ---- explicit-argument leaf functions: mesh.cpp:311-364, texture.cpp:142-156, material.cpp:87-114 ---- */
 void orc_x_get_surface(const orc_mesh* m, uint32_t primId, float i, float j, float k, float normal[3], uint32_t* matIndex,

@@ -135,6 +135,8 @@ def oracle():
     L.orc_scene_set_env_light.restype = None
     L.orc_x_env_sample.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.orc_x_env_sample.restype = None
+    L.orc_set_rr_depth.argtypes = [C.c_uint32]
+    L.orc_set_rr_depth.restype = None
     L.orc_set_anyhit_accounting.argtypes = [C.c_int]
     L.orc_set_anyhit_accounting.restype = None
     L.orc_libm_sincos.argtypes = [C.c_uint32, vp, vp, vp]

@@ -546,3 +546,25 @@ def test_parameter_corners_match_oracle(tracer, spp, max_depth, seed, tile):
     assert_bits_equal(rgb, ref, f"spp {spp} depth {max_depth} seed {seed} tile {tile}")
     for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
         assert st[k] == ost[k], (k, st[k], ost[k])
+
+
+@pytest.mark.parametrize("rr_depth", [0, 2, 9])
+def test_russian_roulette_depth_parameter(tracer, rr_depth):
+    """prt_render_params.rrDepth (4 in the reference, path_tracer.cpp:258): the roulette draw changes the generator stream
+    of every later bounce, so a wrong prefix count shows at once."""
+    scene, camera, exposure = prt_amd.setup_bunny_standin(64, 64, tris=3000)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    t = prt_amd.PathTracer(device=0, max_depth=12, rr_depth=rr_depth, seed=4242)
+    L = T.oracle()
+    try:
+        t.upload_scene(scene)
+        t.set_camera(camera)
+        rgb = t.render(16, exposure=exposure)
+        st = t.last_stats
+        L.orc_set_rr_depth(rr_depth)
+        ref, ost = T.OracleScene(desc).render(16, max_depth=12, seed=4242)
+    finally:
+        L.orc_set_rr_depth(4)
+        t.close()
+    assert_bits_equal(rgb, ref, f"rrDepth {rr_depth}")
+    assert st["raysTraced"] == ost["raysTraced"] and st["occludedTraced"] == ost["occludedTraced"]
