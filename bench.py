@@ -182,7 +182,11 @@ def main():
     setup, kw, W, H, spp, depth, describe = WORKLOADS[args.workload]
     W, H = args.width or W, args.height or H
     spp, depth = args.spp or spp, args.max_depth or depth
-    prt_amd.build()
+    # the library travels prebuilt; should it need a rebuild, one rank does it and the others wait
+    if not use_dist or local_rank == 0:
+        prt_amd.build()
+    if use_dist:
+        dist.barrier()
     scene, camera, exposure = getattr(prt_amd, setup)(W, H, **kw)
     tracer = prt_amd.PathTracer(device=local_rank, max_depth=depth, seed=args.seed)
     tracer.upload_scene(scene)
