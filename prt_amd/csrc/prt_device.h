@@ -12,7 +12,10 @@
 #include "prt_devmath.h"
 
 #define PRT_MAX_BVH 8
-#define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (reference + entry distance: 8 B each)
+#define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (4 B each)
+#ifndef PRT_STACK_LDS_PACKET
+#define PRT_STACK_LDS_PACKET 8 // the same for the packet traversal (8 B each: reference + entry distance)
+#endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
 #ifndef PRT_RULE
@@ -376,36 +379,37 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, V
 // texture path the node and triangle fetches already saturate
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) float lds_f32;
-struct Stack {
+template <int NLDS> // stack entries kept in LDS; deeper ones spill (NLDS a power of two)
+struct StackT {
     lds_u32* ldsRef; // &refs[threadIdx.x]
     lds_f32* ldsT;   // &ts[threadIdx.x]
     uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
     uint32_t spillStride;
     __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
-        if (e < PRT_STACK_LDS) ldsRef[e * PRT_BLOCK] = ref;
-        else spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride] = ref;
+        if (e < NLDS) ldsRef[e * PRT_BLOCK] = ref;
+        else spill[(size_t)(2 * (e - NLDS)) * spillStride] = ref;
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
-        uint32_t v = ldsRef[(e & (PRT_STACK_LDS - 1)) * PRT_BLOCK];
-        if (e >= PRT_STACK_LDS) v = spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride];
+        uint32_t v = ldsRef[(e & (NLDS - 1)) * PRT_BLOCK];
+        if (e >= NLDS) v = spill[(size_t)(2 * (e - NLDS)) * spillStride];
         return v;
     }
     __device__ __forceinline__ void putT(int e, uint32_t ref, float t) const
     {
-        if (e < PRT_STACK_LDS) {
+        if (e < NLDS) {
             ldsRef[e * PRT_BLOCK] = ref;
             ldsT[e * PRT_BLOCK] = t;
         } else {
-            spill[(size_t)(2 * (e - PRT_STACK_LDS)) * spillStride] = ref;
-            spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride] = asu(t);
+            spill[(size_t)(2 * (e - NLDS)) * spillStride] = ref;
+            spill[(size_t)(2 * (e - NLDS) + 1) * spillStride] = asu(t);
         }
     }
     __device__ __forceinline__ float getT(int e) const
     {
-        float v = ldsT[(e & (PRT_STACK_LDS - 1)) * PRT_BLOCK];
-        if (e >= PRT_STACK_LDS) v = asf(spill[(size_t)(2 * (e - PRT_STACK_LDS) + 1) * spillStride]);
+        float v = ldsT[(e & (NLDS - 1)) * PRT_BLOCK];
+        if (e >= NLDS) v = asf(spill[(size_t)(2 * (e - NLDS) + 1) * spillStride]);
         return v;
     }
 };
@@ -523,8 +527,8 @@ __device__ __forceinline__ void tracer_begin(Tracer& T, Vec3 org, Vec3 dir, floa
     T.occ = false;
 }
 
-template <int MODE, bool COUNT>
-__device__ __forceinline__ uint32_t tracer_pop(Tracer& T, const Stack& st, Traffic& tr)
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ uint32_t tracer_pop(Tracer& T, const STK& st, Traffic& tr)
 {
     if (MODE == PRT_MODE_PACKET) {
         while (T.sp > 0) {
@@ -564,8 +568,8 @@ __device__ __forceinline__ bool tracer_next_bvh(const DevScene& sc, Tracer& T, T
 }
 
 // Any-hit modes: both children passed -> the nearer first, the other stacked.
-template <int MODE, bool COUNT>
-__device__ __forceinline__ void tracer_any_hit_order(Tracer& T, const Stack& st, Traffic& tr, const WideNode& w, bool h0, bool h1, bool near0)
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ void tracer_any_hit_order(Tracer& T, const STK& st, Traffic& tr, const WideNode& w, bool h0, bool h1, bool near0)
 {
     if (h0 && h1) {
         st.put(T.sp++, near0 ? w.ref1 : w.ref0);
@@ -585,8 +589,8 @@ struct NodeExt {
     float mx0, mn0, mx1, mn1;
 };
 
-template <int MODE, bool COUNT>
-__device__ __forceinline__ void tracer_decide(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr, const WideNode& w, const NodeExt& e)
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ void tracer_decide(const DevScene& sc, Tracer& T, const STK& st, Traffic& tr, const WideNode& w, const NodeExt& e)
 {
     const float inf = __builtin_inff();
     if (MODE == PRT_MODE_SINGLE) {
@@ -630,8 +634,8 @@ __device__ __forceinline__ void tracer_decide(const DevScene& sc, Tracer& T, con
 }
 
 // One internal node: fetch its 64-byte record, test both children, choose where to go.
-template <int MODE, bool COUNT>
-__device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr, uint32_t& overflow)
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const STK& st, Traffic& tr, uint32_t& overflow)
 {
     WideNode w;
     load_wide(sc, T.ref, w);
@@ -691,8 +695,8 @@ __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const
 // One triangle of the leaf the lane stands on.  A leaf reference is its own cursor: (first triangle, triangles left), so
 // the step leaves the lane on the rest of the leaf or pops.  Stepping triangle by triangle (not leaf by leaf) lets the
 // wave loop regroup lanes after every triangle: a leaf of 8 no longer holds up lanes whose leaf had 1.
-template <int MODE, bool COUNT>
-__device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const Stack& st, Traffic& tr)
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const STK& st, Traffic& tr)
 {
     constexpr bool OCC = (MODE == PRT_MODE_OCC_PACKET || MODE == PRT_MODE_OCC_SINGLE);
     constexpr bool PACKET = (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET);
@@ -735,8 +739,8 @@ __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & PRT_RE
 // leaves are intersected together.
 //   Src: uint32_t count(); uint32_t* cursor(); void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev);
 //        void store_hit(uint32_t i, const DevHit&); void store_occ(uint32_t i, bool);
-template <int MODE, bool COUNT, class Src>
-__device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const Stack& st, Traffic& tr, uint32_t& overflow)
+template <int MODE, bool COUNT, class Src, class STK>
+__device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const STK& st, Traffic& tr, uint32_t& overflow)
 {
     const uint32_t n = src.count();
     const uint32_t lane = threadIdx.x & 63u;

@@ -715,10 +715,13 @@ struct QueueSrc {
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
 {
-    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
-    __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? PRT_STACK_LDS : 1) * PRT_BLOCK];
+    // the packet traversal stacks (reference, entry distance) pairs: half as many entries in the same 16 KB, so that its
+    // blocks do not crowd the other kernels' out of the CU's LDS
+    constexpr int NLDS = (MODE == PRT_MODE_PACKET) ? PRT_STACK_LDS_PACKET : PRT_STACK_LDS;
+    __shared__ uint32_t ldsRef[NLDS * PRT_BLOCK];
+    __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const Stack st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     QueueSrc<MODE> src;
     src.qe = A.qE[MODE];
     src.n = 0;
@@ -811,10 +814,11 @@ struct ArraySrc {
 template <int MODE>
 __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
 {
-    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
-    __shared__ float ldsT[PRT_STACK_LDS * PRT_BLOCK];
+    constexpr int NLDS = (MODE == PRT_MODE_PACKET) ? PRT_STACK_LDS_PACKET : PRT_STACK_LDS;
+    __shared__ uint32_t ldsRef[NLDS * PRT_BLOCK];
+    __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const Stack st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
     ArraySrc src{&A, MODE};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
@@ -999,7 +1003,7 @@ static void wf_iteration(const PartRun& P, uint32_t traceBlocks)
     if (A.sc.hasEnv) hipLaunchKernelGGL((shade_kernel<COUNT, true>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
     else hipLaunchKernelGGL((shade_kernel<COUNT, false>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
     (void)hipEventRecord(P.fork, P.main);
-    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
+    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET);
     WfArgs B = A;
     for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipStreamWaitEvent(P.side[k], P.fork, 0);
     // the three smaller kernels go round the side streams (1: one after the other, 3: each on its own)
@@ -1328,7 +1332,7 @@ static int ensure_launch_resources(prt_hip_ctx* c, uint32_t blocks)
         if (c->spill) (void)hipFree(c->spill);
         c->spill = nullptr;
         // one area per concurrently running trace kernel: four per pipeline
-        HIP_TRY(hipMalloc(&c->spill, 4 * PRT_PARTS * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->spill, 4 * PRT_PARTS * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET) * sizeof(uint32_t)));
         c->spillThreads = threads;
     }
     return PRT_HIP_OK;
@@ -1460,7 +1464,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     // two pipelines as soon as each gets a few tiles; tiny launches keep one
     const int parts = (std::min<uint64_t>(passTiles, totalTiles) >= 4 * PRT_PARTS) ? PRT_PARTS : 1;
     PartRun P[PRT_PARTS];
-    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS);
+    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET);
     {
         uint32_t maxGroups[PRT_PARTS];
         WfArgs L[PRT_PARTS];
