@@ -712,8 +712,18 @@ struct QueueSrc {
 };
 
 // Persistent lanes over one ray queue.  MODE = the queue id = the traversal mode.
+// Waves per SIMD the trace kernels are compiled for.  Without a bound the compiler takes 112 SGPRs, which caps a SIMD at 6 waves
+// (800 SGPRs per SIMD, MI355X_MICROARCH.md "Occupancy API"); 7 gives 94 SGPRs / 72 VGPRs with no spills and the best frame time
+// (C3: unbounded 533 ms, 8: 521 with 9 SGPR spills, 7: 514, 6 and 5: 535).
+#ifndef PRT_TRACE_WAVES
+#define PRT_TRACE_WAVES 7
+#endif
 template <int MODE, bool COUNT>
+#if PRT_TRACE_WAVES
+__global__ __launch_bounds__(PRT_BLOCK, PRT_TRACE_WAVES) void trace_kernel(WfArgs A)
+#else
 __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
+#endif
 {
     // the packet traversal stacks (reference, entry distance) pairs: half as many entries in the same 16 KB, so that its
     // blocks do not crowd the other kernels' out of the CU's LDS
