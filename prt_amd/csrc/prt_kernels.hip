@@ -125,6 +125,9 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
+#ifndef PRT_SHADE_WAVES
+#define PRT_SHADE_WAVES 7 // waves per SIMD the shade kernel is compiled for (C3: 8: 514 ms, 7: 507, 6 and 5: 514, 4: 523)
+#endif
 #ifndef PRT_TRACE_BPC
 #define PRT_TRACE_BPC 4 // persistent blocks per CU and trace kernel
 #endif
@@ -210,7 +213,7 @@ struct WfArgs {
 #endif
 
 template <bool COUNT, bool ENV>
-__global__ __launch_bounds__(PRT_BLOCK, 8) void shade_kernel(WfArgs A)
+__global__ __launch_bounds__(PRT_BLOCK, PRT_SHADE_WAVES) void shade_kernel(WfArgs A)
 {
 #ifdef PRT_STAMP
     unsigned long long stampAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
