@@ -18,20 +18,8 @@
 #endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
-#ifndef PRT_RULE
-#define PRT_RULE 0
-#endif
-#ifndef PRT_STAY
-#define PRT_STAY 24
-#endif
-#ifndef PRT_NODE_W
-#define PRT_NODE_W 1
-#endif
-#ifndef PRT_LEAF_W
-#define PRT_LEAF_W 1
-#endif
 #ifndef PRT_TRI2
-#define PRT_TRI2 1
+#define PRT_TRI2 1 // a leaf step tests two triangles (one: 569 ms against 547 on C3)
 #endif
 #ifndef PRT_IDLE_BREAK
 #define PRT_IDLE_BREAK 8 // lanes without a node or triangle to step on that send the wave back to the refill point
@@ -813,19 +801,12 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
         // Step phase: a step is one internal node or one triangle.  Each round the larger of the two groups of lanes steps
         // (the other waits: SIMD lanes that cannot share an instruction stream), until PRT_IDLE_BREAK lanes have nothing
         // to step on -- their ray is finished or moves to the next BVH -- and the wave goes back to the top to serve them.
-        bool lastNode = true;
         for (;;) {
             const bool onNode = active && ref_is_internal(T.ref);
             const bool onLeaf = active && ref_is_leaf(T.ref);
             const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
             if (nNode + nLeaf == 0u) break;
-#if PRT_RULE == 1
-            const bool keep = (lastNode ? nNode : nLeaf) >= PRT_STAY;
-            const bool doNode = keep ? lastNode : (nNode >= nLeaf);
-            lastNode = doNode;
-#else
-            const bool doNode = nNode * PRT_NODE_W >= nLeaf * PRT_LEAF_W;
-#endif
+            const bool doNode = nNode >= nLeaf; // weighting either side, or staying with one kind while it has 16-32 lanes, measured slower
             if (doNode) {
                 if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
             } else {
