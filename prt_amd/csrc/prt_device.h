@@ -18,6 +18,7 @@
 #endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #define PRT_BLOCK 256
+#define PRT_MAT_STRIDE 5 // float4 per material record
 #ifndef PRT_TRI2
 #define PRT_TRI2 1 // a leaf step tests two triangles (one: 569 ms against 547 on C3)
 #endif
@@ -34,7 +35,8 @@
 // shade:  4 x float4 per triangle in MESH order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
 //         (n0 = precomputed face normal when the mesh has no vertex normals)
 // bump:   3 x float4 per triangle in mesh order {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
-// mats:   3 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0}
+// mats:   5 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0} {descriptor of the diffuse map} {... of the bump map}
+//         (descriptor = {byte offset, width, height, component}, as in texDesc)
 // alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
 struct DevScene {
     const float4* wnodes;
@@ -322,9 +324,8 @@ __device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint32_t tex,
 }
 
 template <bool COUNT>
-__device__ __forceinline__ Vec3 tex_sample3(const DevScene& sc, uint32_t tex, Vec2 uv, Traffic& tr)
+__device__ __forceinline__ Vec3 tex_sample3(const DevScene& sc, uint4 d, Vec2 uv, Traffic& tr)
 {
-    uint4 d = sc.texDesc[tex];
     const uint8_t* p = sc.texels + d.x;
     float k[4];
     int32_t idx[4];
@@ -340,9 +341,8 @@ __device__ __forceinline__ Vec3 tex_sample3(const DevScene& sc, uint32_t tex, Ve
 }
 
 template <bool COUNT>
-__device__ __forceinline__ float tex_sample1(const DevScene& sc, uint32_t tex, Vec2 uv, Traffic& tr)
+__device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 uv, Traffic& tr)
 {
-    uint4 d = sc.texDesc[tex];
     const uint8_t* p = sc.texels + d.x;
     float k[4];
     int32_t idx[4];
@@ -908,12 +908,13 @@ __device__ __forceinline__ void env_sample(const DevScene& sc, float ux, float u
 template <bool COUNT>
 __device__ __forceinline__ Vec3 sample_diffuse(const DevScene& sc, uint32_t mat, Vec2 uv, Traffic& tr)
 {
-    const float4* mp = sc.mats + 3 * (size_t)mat;
-    float4 m0 = mp[0], m2 = mp[2];
+    // the material record carries the descriptors of its two maps: material and descriptor arrive in one round trip
+    const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)mat;
+    float4 m0 = mp[0], m2 = mp[2], m3 = mp[3];
     Vec3 color = mk3(m0.x, m0.y, m0.z);
     int32_t tex = (int32_t)asu(m2.x);
     if (tex >= 0) {
-        Vec3 c = tex_sample3<COUNT>(sc, (uint32_t)tex, uv, tr);
+        Vec3 c = tex_sample3<COUNT>(sc, make_uint4(asu(m3.x), asu(m3.y), asu(m3.z), asu(m3.w)), uv, tr);
         color = mul3(color, mk3(prt_powf_2p2(c.x), prt_powf_2p2(c.y), prt_powf_2p2(c.z)));
     }
     return color;
@@ -924,18 +925,19 @@ template <bool COUNT>
 __device__ __forceinline__ Vec3 sample_bump(const DevScene& sc, uint32_t mat, const Surface& s, Traffic& tr)
 {
     Vec3 normal = s.normal;
-    const float4* mp = sc.mats + 3 * (size_t)mat;
-    int32_t tex = (int32_t)asu(mp[2].y);
+    const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)mat;
+    float4 m2 = mp[2], m4 = mp[4];
+    int32_t tex = (int32_t)asu(m2.y);
     if (tex >= 0) {
         const float4* bp = sc.bump + 3 * (size_t)s.prim;
         float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
         Vec3 dp01 = mk3(b0.x, b0.y, b0.z), dp02 = mk3(b1.x, b1.y, b1.z);
         Vec2 duv01 = Vec2{b0.w, b1.w}, duv02 = Vec2{b2.x, b2.y};
-        uint4 d = sc.texDesc[tex];
+        const uint4 d = make_uint4(asu(m4.x), asu(m4.y), asu(m4.z), asu(m4.w));
         float onePixel = 0.5f / (float)(int32_t)d.y + 0.5f / (float)(int32_t)d.z; // texture.h:26
-        float b = tex_sample1<COUNT>(sc, (uint32_t)tex, s.uv, tr);
-        float b01 = tex_sample1<COUNT>(sc, (uint32_t)tex, Vec2{s.uv.x + onePixel * duv01.x, s.uv.y + onePixel * duv01.y}, tr) - b;
-        float b02 = tex_sample1<COUNT>(sc, (uint32_t)tex, Vec2{s.uv.x + onePixel * duv02.x, s.uv.y + onePixel * duv02.y}, tr) - b;
+        float b = tex_sample1<COUNT>(sc, d, s.uv, tr);
+        float b01 = tex_sample1<COUNT>(sc, d, Vec2{s.uv.x + onePixel * duv01.x, s.uv.y + onePixel * duv01.y}, tr) - b;
+        float b02 = tex_sample1<COUNT>(sc, d, Vec2{s.uv.x + onePixel * duv02.x, s.uv.y + onePixel * duv02.y}, tr) - b;
         float nk = 4.0f;
         normal = normalize3(add3(add3(normal, scale3(nk * b01, dp01)), scale3(nk * b02, dp02)));
     }

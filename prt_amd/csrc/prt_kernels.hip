@@ -241,7 +241,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_SHADE_WAVES) void shade_kernel(WfArg
     const uint32_t aliveAtEntry = (phase == PH_WAIT_BOUNCE) ? alive : 0u;
     uint32_t rng = 0, pixel = 0xffffffffu;
     Vec3 color = mk3(0, 0, 0);
-    if (phase != PH_DONE) {
+    if (inRange) { // with gInfo, not after it: one round trip (a finished group reads three words it will not use)
         rng = A.gRng[g];
         pixel = A.gPixel[g];
         float4 c = A.gColor[g];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_SHADE_WAVES) void shade_kernel(WfArg
         const bool active = slot < alive;
         uint32_t rtype = 2u;
         if (active) {
-            const float4* mp = sc.mats + 3 * (size_t)material;
+            const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)material;
             float4 m0 = mp[0], m1 = mp[1];
             rtype = asu(m0.w);
             if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
@@ -1158,7 +1158,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         if (!md.nodes || !md.primRemapping || !md.indices || !md.positions || !md.primMaterial || !md.materials || md.nodeCount == 0)
             return fail(PRT_HIP_EINVAL, "mesh descriptor has NULL arrays");
         const uint32_t triBase = (uint32_t)(tris.size() / 3);
-        const uint32_t primBase = (uint32_t)(shade.size() / 4), matBase = (uint32_t)(mats.size() / 3);
+        const uint32_t primBase = (uint32_t)(shade.size() / 4), matBase = (uint32_t)(mats.size() / PRT_MAT_STRIDE);
         sc.primBase[m] = primBase;
         sc.hasNormals[m] = md.normals ? 1u : 0u;
         auto P = [&](uint32_t v) { return HVec3{md.positions[3 * v], md.positions[3 * v + 1], md.positions[3 * v + 2]}; };
@@ -1170,6 +1170,10 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             mats.push_back(make_float4(mt.diffuse[0], mt.diffuse[1], mt.diffuse[2], ubits(mt.reflectionType)));
             mats.push_back(make_float4(mt.emissive[0], mt.emissive[1], mt.emissive[2], ubits(mt.alphaTest)));
             mats.push_back(make_float4(ubits((uint32_t)mt.diffuseMap), ubits((uint32_t)mt.bumpMap), 0.0f, 0.0f));
+            for (int32_t tex : {mt.diffuseMap, mt.bumpMap}) {
+                const uint4 d = tex >= 0 ? texDesc[tex] : make_uint4(0, 0, 0, 0);
+                mats.push_back(make_float4(ubits(d.x), ubits(d.y), ubits(d.z), ubits(d.w)));
+            }
         }
         // Wide records: one per internal node, in the reference's DFS order.  wideIndex[i] = record of node i.
         {
