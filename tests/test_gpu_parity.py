@@ -568,3 +568,26 @@ def test_russian_roulette_depth_parameter(tracer, rr_depth):
         t.close()
     assert_bits_equal(rgb, ref, f"rrDepth {rr_depth}")
     assert st["raysTraced"] == ost["raysTraced"] and st["occludedTraced"] == ost["occludedTraced"]
+
+
+def test_cpp_drop_in_driver_matches_python_host(tracer, tmp_path):
+    """examples/main.cpp -- the reference's main.cpp call sequence compiled against prt_amd/csrc/host/prt.h (the drop-in
+    C++ surface: Scene/Camera/Mesh/Bvh/Image/PathTracer) -- renders the bunny-class scene; its float image must equal
+    the one the ctypes host produces through the C-ABI, bit for bit."""
+    import subprocess
+    ex = os.path.join(T.ROOT, "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    W, H, spp = 160, 120, 16
+    out = subprocess.run([os.path.join(ex, "prt_main"), "bunny", str(W), str(H), str(spp)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    with open(tmp_path / "render.pfm", "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        assert float(f.readline()) < 0  # little-endian
+        img = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1]  # PFM rows run bottom to top
+    scene, camera, exposure = prt_amd.setup_bunny_standin(W, H, tris=69451)
+    upload(tracer, scene, camera)
+    ref = tracer.render(spp, exposure=exposure)
+    assert (w, h) == (W, H)
+    assert_bits_equal(np.ascontiguousarray(img), ref, "C++ driver vs Python host")
+    assert f"{tracer.last_stats['raysTraced']} rays" in out.stdout
