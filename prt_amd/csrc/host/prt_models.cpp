@@ -153,14 +153,14 @@ bool parseObj(const char* path, ObjData& o)
     return true;
 }
 
-// Binary PPM (P6, 3 components -> RGBA with alpha 255), PGM (P5) and PAM (P7 RGB_ALPHA) textures.
-bool loadPnm(const std::string& path, Texture& tex, bool bump)
+// Decoders of the two 8-bit image families this build reads without stb: rows top to bottom, `depth` interleaved components.
+// Binary PPM (P6), PGM (P5) and PAM (P7) ...
+static bool decodePnm(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>& raw)
 {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
     char magic[3] = {0, 0, 0};
-    int w = 0, h = 0, maxv = 255, depth = 0;
-    if (fscanf(f, "%2s", magic) != 1) { fclose(f); return false; }
+    int maxv = 255;
+    w = h = depth = 0;
+    if (fscanf(f, "%2s", magic) != 1) return false;
     if (!strcmp(magic, "P7")) {
         char key[64];
         while (fscanf(f, "%63s", key) == 1) {
@@ -173,17 +173,81 @@ bool loadPnm(const std::string& path, Texture& tex, bool bump)
         }
     } else if (!strcmp(magic, "P6") || !strcmp(magic, "P5")) {
         depth = magic[1] == '6' ? 3 : 1;
-        if (fscanf(f, "%d %d %d", &w, &h, &maxv) != 3) { fclose(f); return false; }
+        if (fscanf(f, "%d %d %d", &w, &h, &maxv) != 3) return false;
     } else {
-        fclose(f);
         return false;
     }
     fgetc(f);
-    if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || maxv != 255 || depth < 1 || depth > 4) { fclose(f); return false; }
-    std::vector<uint8_t> raw((size_t)w * h * depth);
-    bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || maxv != 255 || depth < 1 || depth > 4) return false;
+    raw.resize((size_t)w * h * depth);
+    return fread(raw.data(), 1, raw.size(), f) == raw.size();
+}
+
+// ... and Truevision TGA: true-colour (type 2) and grey (type 3), raw or run-length encoded (10, 11), 8 / 24 / 32 bits per
+// pixel, either row order, either column order.  Colour-mapped and 15/16-bit files are not read.  Stored BGR(A) -> RGB(A).
+static bool decodeTga(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>& raw)
+{
+    uint8_t hd[18];
+    if (fread(hd, 1, 18, f) != 18) return false;
+    const int idLength = hd[0], colorMapType = hd[1], type = hd[2], bpp = hd[16], desc = hd[17];
+    w = hd[12] | (hd[13] << 8);
+    h = hd[14] | (hd[15] << 8);
+    const bool rle = (type == 10 || type == 11), grey = (type == 3 || type == 11);
+    if (colorMapType != 0 || !(type == 2 || type == 3 || rle) || w <= 0 || h <= 0) return false;
+    if (!((grey && bpp == 8) || (!grey && (bpp == 24 || bpp == 32)))) return false;
+    depth = bpp / 8;
+    if (fseek(f, idLength, SEEK_CUR) != 0) return false;
+    const size_t n = (size_t)w * h;
+    std::vector<uint8_t> px(n * depth);
+    if (!rle) {
+        if (fread(px.data(), 1, px.size(), f) != px.size()) return false;
+    } else {
+        size_t i = 0;
+        while (i < n) {
+            int c = fgetc(f);
+            if (c == EOF) return false;
+            size_t count = (size_t)(c & 0x7f) + 1;
+            if (i + count > n) return false;
+            if (c & 0x80) { // run: one pixel repeated
+                uint8_t v[4];
+                if (fread(v, 1, depth, f) != (size_t)depth) return false;
+                for (size_t k = 0; k < count; k++) memcpy(&px[(i + k) * depth], v, depth);
+            } else if (fread(&px[i * depth], 1, count * depth, f) != count * depth) {
+                return false;
+            }
+            i += count;
+        }
+    }
+    const bool topDown = (desc & 0x20) != 0, rightLeft = (desc & 0x10) != 0;
+    raw.resize(n * depth);
+    for (int y = 0; y < h; y++) {
+        const int sy = topDown ? y : h - 1 - y;
+        for (int x = 0; x < w; x++) {
+            const int sx = rightLeft ? w - 1 - x : x;
+            const uint8_t* s = &px[((size_t)sy * w + sx) * depth];
+            uint8_t* d = &raw[((size_t)y * w + x) * depth];
+            if (depth == 1) d[0] = s[0];
+            else {
+                d[0] = s[2]; d[1] = s[1]; d[2] = s[0];
+                if (depth == 4) d[3] = s[3];
+            }
+        }
+    }
+    return true;
+}
+
+// Texture::load (texture.cpp:212-254) without stb_image: PNM or TGA by content.
+bool loadTexture(const std::string& path, Texture& tex, bool bump)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int w = 0, h = 0, depth = 0;
+    std::vector<uint8_t> raw;
+    int c0 = fgetc(f);
+    ungetc(c0, f);
+    bool ok = (c0 == 'P') ? decodePnm(f, w, h, depth, raw) : decodeTga(f, w, h, depth, raw);
     fclose(f);
-    if (!ok) return false;
+    if (!ok || w > 65535 || h > 65535) return false;
     // texture.cpp:226-247: grey stays 1 component, everything else becomes RGBA; 3-component bump maps become
     // a 1-component height field (convertNormalToBump, texture.cpp:185-200)
     if (depth == 1) {
@@ -247,8 +311,8 @@ void parseMtl(const std::string& path, const std::string& dir, const std::vector
                 if (c == '\\') c = '/';
             bool bump = key != "map_Kd";
             Texture& t = bump ? cur->bumpMap : cur->diffuseMap;
-            if (!loadPnm(dir + "/" + name, t, bump))
-                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM only: stb is not vendored)\n", name.c_str());
+            if (!loadTexture(dir + "/" + name, t, bump))
+                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM and TGA only: stb is not vendored)\n", name.c_str());
         }
     }
     for (auto& m : mats) m.alphaTest = m.diffuseMap.isAlphaTestRequired(); // material.cpp:79

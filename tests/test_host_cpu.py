@@ -190,3 +190,63 @@ def test_infinite_area_light_tables_match_oracle(L, tmp_path):
     with pytest.raises(prt_amd.PrtError):
         scene3.set_infinite_area_light(str(tmp_path / "missing.pfm"))
     assert scene3.arrays()["env"] is None
+
+
+def _tga(path, img, rle=False, top_down=False):
+    """Write an 8-bit grey (h, w) or true-colour (h, w, 3|4) image as a TGA file."""
+    import struct
+    h, w = img.shape[:2]
+    depth = 1 if img.ndim == 2 else img.shape[2]
+    px = img.reshape(h, w, depth)
+    if depth >= 3:
+        px = px[..., [2, 1, 0] + ([3] if depth == 4 else [])]  # stored BGR(A)
+    rows = px if top_down else px[::-1]
+    flat = np.ascontiguousarray(rows).reshape(-1, depth)
+    typ = (3 if depth == 1 else 2) + (8 if rle else 0)
+    body = bytearray()
+    if rle:
+        i, n = 0, len(flat)
+        while i < n:
+            run = 1
+            while i + run < n and run < 128 and (flat[i + run] == flat[i]).all():
+                run += 1
+            if run >= 2:
+                body += bytes([0x80 | (run - 1)]) + flat[i].tobytes()
+                i += run
+            else:
+                lit = 1
+                while i + lit < n and lit < 128 and not (i + lit + 1 < n and (flat[i + lit] == flat[i + lit + 1]).all()):
+                    lit += 1
+                body += bytes([lit - 1]) + flat[i:i + lit].tobytes()
+                i += lit
+    else:
+        body += flat.tobytes()
+    with open(path, "wb") as f:
+        f.write(struct.pack("<BBBHHBHHHHBB", 3, 0, typ, 0, 0, 0, 0, 0, w, h, 8 * depth, (0x20 if top_down else 0) | (8 if depth == 4 else 0)))
+        f.write(b"id!")
+        f.write(bytes(body))
+
+
+@pytest.mark.parametrize("rle", [False, True])
+@pytest.mark.parametrize("top_down", [False, True])
+def test_obj_mtl_reader_decodes_tga_maps(L, tmp_path, rle, top_down):
+    """map_Kd / map_bump through TGA files (true-colour with alpha, grey; raw and run-length encoded; both row orders):
+    texels reach the scene descriptor as Texture::load would deliver them (RGBA for colour, one component for grey,
+    texture.cpp:226-247), and the alpha channel switches the alpha test on (material.cpp:79)."""
+    rng = np.random.default_rng(3)
+    kd = rng.integers(0, 256, size=(6, 9, 4), dtype=np.uint8)
+    kd[2:4, :, :] = kd[2, 0]            # runs for the RLE path
+    kd[..., 3] = np.where(rng.random((6, 9)) < 0.5, 255, 40)
+    bump = rng.integers(0, 256, size=(5, 7), dtype=np.uint8)
+    bump[1] = 77
+    _tga(tmp_path / "kd.tga", kd, rle, top_down)
+    _tga(tmp_path / "bump.tga", bump, rle, top_down)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd kd.tga\nmap_bump -bm 1.0 bump.tga\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    scene = prt_amd.Scene()
+    scene.add(prt_amd.Mesh.load_obj(str(tmp_path / "m.obj")))
+    a = scene.arrays()
+    mats = a["meshes"][0]["materials"]
+    assert len(a["textures"]) == 2 and int(mats["alphaTest"][0]) == 1
+    assert np.array_equal(a["textures"][int(mats["diffuseMap"][0])], kd)
+    assert np.array_equal(a["textures"][int(mats["bumpMap"][0])][..., 0], bump)
