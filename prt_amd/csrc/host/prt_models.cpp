@@ -236,7 +236,200 @@ static bool decodeTga(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
     return true;
 }
 
-// Texture::load (texture.cpp:212-254) without stb_image: PNM or TGA by content.
+// ... and PNG: 8 bits per sample, grey / grey+alpha / RGB / RGBA / palette (with tRNS), not interlaced.  A plain inflate
+// (RFC 1951: stored, fixed and dynamic Huffman blocks) and the five scanline filters (PNG 1.2 section 6).
+namespace {
+struct BitReader {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint32_t buf = 0;
+    int cnt = 0;
+    bool fail = false;
+    int bits(int k)
+    {
+        while (cnt < k) {
+            if (pos >= n) { fail = true; return 0; }
+            buf |= (uint32_t)p[pos++] << cnt;
+            cnt += 8;
+        }
+        int v = (int)(buf & ((1u << k) - 1u));
+        buf >>= k;
+        cnt -= k;
+        return v;
+    }
+};
+struct Huffman {
+    uint16_t count[16], symbol[288];
+    void build(const uint8_t* len, int n)
+    {
+        memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + count[i];
+        for (int i = 0; i < n; i++)
+            if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader& br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= br.bits(1);
+            if (br.fail) return -1;
+            int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+bool inflateZlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
+{
+    if (in.size() < 6) return false;
+    BitReader br{in.data() + 2, in.size() - 2}; // skip the zlib header (CMF, FLG); the Adler-32 trailer is not checked
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+        int last = br.bits(1), type = br.bits(2);
+        if (br.fail) return false;
+        if (type == 0) {
+            br.buf = 0; br.cnt = 0;
+            if (br.pos + 4 > br.n) return false;
+            size_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            uint8_t lens[320];
+            if (type == 1) {
+                for (int i = 0; i < 288; i++) lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                lit.build(lens, 288);
+                for (int i = 0; i < 30; i++) lens[i] = 5;
+                dist.build(lens, 30);
+            } else {
+                int nlen = br.bits(5) + 257, ndist = br.bits(5) + 1, ncode = br.bits(4) + 4;
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t cl[19] = {0};
+                for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+                Huffman clh;
+                clh.build(cl, 19);
+                int i = 0;
+                while (i < nlen + ndist) {
+                    int sym = clh.decode(br);
+                    if (sym < 0) return false;
+                    if (sym < 16) lens[i++] = (uint8_t)sym;
+                    else {
+                        int rep = sym == 16 ? 3 + br.bits(2) : sym == 17 ? 3 + br.bits(3) : 11 + br.bits(7);
+                        uint8_t v = (sym == 16 && i > 0) ? lens[i - 1] : 0;
+                        if (sym == 16 && i == 0) return false;
+                        if (i + rep > nlen + ndist) return false;
+                        while (rep--) lens[i++] = v;
+                    }
+                }
+                lit.build(lens, nlen);
+                dist.build(lens + nlen, ndist);
+            }
+            for (;;) {
+                int sym = lit.decode(br);
+                if (sym < 0 || br.fail) return false;
+                if (sym < 256) out.push_back((uint8_t)sym);
+                else if (sym == 256) break;
+                else {
+                    sym -= 257;
+                    if (sym >= 29) return false;
+                    int len = lbase[sym] + br.bits(lext[sym]);
+                    int ds = dist.decode(br);
+                    if (ds < 0 || ds >= 30) return false;
+                    size_t d = dbase[ds] + (size_t)br.bits(dext[ds]);
+                    if (d > out.size()) return false;
+                    for (int k = 0; k < len; k++) out.push_back(out[out.size() - d]);
+                }
+            }
+        } else {
+            return false;
+        }
+        if (last) return !br.fail;
+    }
+}
+} // namespace
+
+static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>& raw)
+{
+    std::vector<uint8_t> file;
+    uint8_t tmp[65536];
+    for (size_t n; (n = fread(tmp, 1, sizeof(tmp), f)) > 0;) file.insert(file.end(), tmp, tmp + n);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8)) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | (file[o + 1] << 16) | (file[o + 2] << 8) | file[o + 3]; };
+    int colorType = -1;
+    std::vector<uint8_t> idat, palette, trns;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        uint32_t len = be32(o);
+        if (o + 12 + (size_t)len > file.size()) return false;
+        const uint8_t* d = &file[o + 8];
+        if (!memcmp(&file[o + 4], "IHDR", 4)) {
+            if (len < 13) return false;
+            w = (int)be32(o + 8);
+            h = (int)be32(o + 12);
+            if (d[8] != 8 || d[10] != 0 || d[11] != 0 || d[12] != 0) return false; // 8 bits per sample, no interlace
+            colorType = d[9];
+        } else if (!memcmp(&file[o + 4], "PLTE", 4)) palette.assign(d, d + len);
+        else if (!memcmp(&file[o + 4], "tRNS", 4)) trns.assign(d, d + len);
+        else if (!memcmp(&file[o + 4], "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+        else if (!memcmp(&file[o + 4], "IEND", 4)) break;
+        o += 12 + (size_t)len;
+    }
+    const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
+    if (!channels || w <= 0 || h <= 0 || w > 65535 || h > 65535) return false;
+    std::vector<uint8_t> data;
+    if (!inflateZlib(idat, data)) return false;
+    const size_t stride = (size_t)w * channels;
+    if (data.size() < (stride + 1) * (size_t)h) return false;
+    std::vector<uint8_t> img(stride * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* src = &data[(stride + 1) * y];
+        uint8_t* cur = &img[stride * y];
+        const uint8_t* up = y ? cur - stride : nullptr;
+        const int ft = src[0];
+        if (ft > 4) return false;
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= (size_t)channels ? cur[i - channels] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)channels) ? up[i - channels] : 0, pr = 0;
+            if (ft == 1) pr = a;
+            else if (ft == 2) pr = b;
+            else if (ft == 3) pr = (a + b) >> 1;
+            else if (ft == 4) {
+                int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            cur[i] = (uint8_t)(src[1 + i] + pr);
+        }
+    }
+    if (colorType == 3) { // palette -> RGB(A)
+        if (palette.size() < 3) return false;
+        depth = trns.empty() ? 3 : 4;
+        raw.resize((size_t)w * h * depth);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            size_t k = img[i];
+            if (3 * k + 2 >= palette.size()) return false;
+            raw[depth * i + 0] = palette[3 * k]; raw[depth * i + 1] = palette[3 * k + 1]; raw[depth * i + 2] = palette[3 * k + 2];
+            if (depth == 4) raw[depth * i + 3] = k < trns.size() ? trns[k] : 255;
+        }
+    } else {
+        depth = channels;
+        raw.swap(img);
+    }
+    return true;
+}
+
+// Texture::load (texture.cpp:212-254) without stb_image: PNM, PNG or TGA by content.
 bool loadTexture(const std::string& path, Texture& tex, bool bump)
 {
     FILE* f = fopen(path.c_str(), "rb");
@@ -245,7 +438,7 @@ bool loadTexture(const std::string& path, Texture& tex, bool bump)
     std::vector<uint8_t> raw;
     int c0 = fgetc(f);
     ungetc(c0, f);
-    bool ok = (c0 == 'P') ? decodePnm(f, w, h, depth, raw) : decodeTga(f, w, h, depth, raw);
+    bool ok = (c0 == 'P') ? decodePnm(f, w, h, depth, raw) : (c0 == 0x89) ? decodePng(f, w, h, depth, raw) : decodeTga(f, w, h, depth, raw);
     fclose(f);
     if (!ok || w > 65535 || h > 65535) return false;
     // texture.cpp:226-247: grey stays 1 component, everything else becomes RGBA; 3-component bump maps become
@@ -312,7 +505,7 @@ void parseMtl(const std::string& path, const std::string& dir, const std::vector
             bool bump = key != "map_Kd";
             Texture& t = bump ? cur->bumpMap : cur->diffuseMap;
             if (!loadTexture(dir + "/" + name, t, bump))
-                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM and TGA only: stb is not vendored)\n", name.c_str());
+                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM, 8-bit PNG and TGA only: stb is not vendored)\n", name.c_str());
         }
     }
     for (auto& m : mats) m.alphaTest = m.diffuseMap.isAlphaTestRequired(); // material.cpp:79

@@ -250,3 +250,78 @@ def test_obj_mtl_reader_decodes_tga_maps(L, tmp_path, rle, top_down):
     assert len(a["textures"]) == 2 and int(mats["alphaTest"][0]) == 1
     assert np.array_equal(a["textures"][int(mats["diffuseMap"][0])], kd)
     assert np.array_equal(a["textures"][int(mats["bumpMap"][0])][..., 0], bump)
+
+
+def _png(path, img, level=6, strategy=0, palette=None, trns=None):
+    """Write an 8-bit PNG (grey, grey+alpha, RGB, RGBA or palette) cycling through the five scanline filters."""
+    import struct
+    import zlib
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    ctype = 3 if palette is not None else {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    out = bytearray()
+    for y in range(h):
+        ft = y % 5
+        cur, up = rows[y], (rows[y - 1] if y else np.zeros(w * ch, dtype=np.int32))
+        a = np.concatenate([np.zeros(ch, dtype=np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, dtype=np.int32), up[:-ch]])
+        if ft == 0: pred = 0
+        elif ft == 1: pred = a
+        elif ft == 2: pred = up
+        elif ft == 3: pred = (a + up) // 2
+        else:
+            p = a + up - c
+            pa, pb, pc = abs(p - a), abs(p - up), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, up, c))
+        out += bytes([ft]) + ((cur - pred) & 0xff).astype(np.uint8).tobytes()
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+    z = co.compress(bytes(out)) + co.flush()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)))
+        if palette is not None:
+            f.write(chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes()))
+            if trns is not None:
+                f.write(chunk(b"tRNS", np.asarray(trns, dtype=np.uint8).tobytes()))
+        half = len(z) // 2
+        f.write(chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("level,strategy", [(0, 0), (1, 0), (9, 0), (6, 4)])  # stored, dynamic Huffman, fixed Huffman (Z_FIXED)
+def test_obj_mtl_reader_decodes_png_maps(L, tmp_path, level, strategy):
+    rng = np.random.default_rng(5)
+    kd = rng.integers(0, 256, size=(13, 11, 4), dtype=np.uint8)
+    kd[3:9, 2:9] = kd[3, 2]  # long matches for the LZ77 path
+    kd[..., 3] = np.where(rng.random((13, 11)) < 0.5, 255, 17)
+    grey = (np.arange(19 * 7, dtype=np.uint32).reshape(7, 19) * 7 % 256).astype(np.uint8)
+    _png(tmp_path / "kd.png", kd, level, strategy)
+    _png(tmp_path / "bump.png", grey, level, strategy)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd kd.png\nmap_bump bump.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    scene = prt_amd.Scene()
+    scene.add(prt_amd.Mesh.load_obj(str(tmp_path / "m.obj")))
+    a = scene.arrays()
+    mats = a["meshes"][0]["materials"]
+    assert np.array_equal(a["textures"][int(mats["diffuseMap"][0])], kd) and int(mats["alphaTest"][0]) == 1
+    assert np.array_equal(a["textures"][int(mats["bumpMap"][0])][..., 0], grey)
+    # RGB (no alpha -> 255, no alpha test), grey + alpha, and a palette with transparency
+    rgb = rng.integers(0, 256, size=(5, 6, 3), dtype=np.uint8)
+    ga = rng.integers(0, 256, size=(4, 5, 2), dtype=np.uint8)
+    pal = rng.integers(0, 256, size=(7, 3), dtype=np.uint8)
+    idx = rng.integers(0, 7, size=(6, 4), dtype=np.uint8)
+    tr = np.array([255, 0, 128], dtype=np.uint8)
+    _png(tmp_path / "rgb.png", rgb, level, strategy)
+    _png(tmp_path / "ga.png", ga, level, strategy)
+    _png(tmp_path / "pal.png", idx, level, strategy, palette=pal, trns=tr)
+    for name, want in (("rgb", np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)])),
+                       ("ga", np.dstack([ga[..., 0], ga[..., 0], ga[..., 0], ga[..., 1]])),
+                       ("pal", np.dstack([pal[idx], np.where(idx < 3, tr[np.minimum(idx, 2)], 255).astype(np.uint8)]))):
+        (tmp_path / "n.mtl").write_text(f"newmtl a\nKd 1 1 1\nmap_Kd {name}.png\n")
+        (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+        sc = prt_amd.Scene()
+        sc.add(prt_amd.Mesh.load_obj(str(tmp_path / "n.obj")))
+        b = sc.arrays()
+        assert np.array_equal(b["textures"][0], want), name
