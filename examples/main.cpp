@@ -97,7 +97,8 @@ int main(int argc, char** argv)
     auto st = tracer.getStats();
     printf("%.3fms @%uspp, %llu rays (%llu occlusion), kernels %.3f ms => %.1f Mray/s\n", ms, kSamples, (unsigned long long)st.raysTraced,
            (unsigned long long)st.occludedTraced, tracer.getKernelMs(), st.raysTraced / tracer.getKernelMs() / 1e3);
-    image.saveExr("render");      // writes render.pfm (raw float)
+    image.saveExr("render.exr");  // main.cpp:189
+    image.savePfm("render.pfm");  // the same pixels as raw floats
     image.savePpm("render.ppm");
     PathTracer::releaseDevice();
     return 0;

@@ -51,6 +51,11 @@ int prt_host_scene_load_env_light(prt_host_scene* s, const char* path);
 const prt_scene_desc* prt_host_scene_describe(prt_host_scene* s);
 void prt_host_scene_bbox(const prt_host_scene* s, float lowerUpper[6]);
 
+/* Image::saveExr (image.cpp:82-139: half-float B,G,R OpenEXR) and Image::savePpm (image.cpp:52-80: tone map, gamma, 8 bit)
+ * for a float RGB image of width*height*3 values, row 0 first; 0 or -1 */
+int prt_host_save_exr(const char* path, uint32_t width, uint32_t height, const float* rgb);
+int prt_host_save_ppm(const char* path, uint32_t width, uint32_t height, const float* rgb, int tonemap);
+
 /* Camera::create (camera.h:17-36) */
 void prt_host_camera_create(const float pos[3], const float dir[3], uint32_t width, uint32_t height,
                             prt_camera_desc* out);

@@ -109,7 +109,7 @@ EXPORTS = [
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
     "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
     "prt_host_mesh_calculate_bounds", "prt_host_mesh_prim_count", "prt_host_scene_create", "prt_host_scene_destroy",
-    "prt_host_scene_add_mesh", "prt_host_scene_set_directional_light", "prt_host_scene_set_env_light", "prt_host_scene_load_env_light", "prt_host_scene_describe", "prt_host_scene_bbox",
+    "prt_host_scene_add_mesh", "prt_host_scene_set_directional_light", "prt_host_scene_set_env_light", "prt_host_scene_load_env_light", "prt_host_scene_describe", "prt_host_scene_bbox", "prt_host_save_exr", "prt_host_save_ppm",
     "prt_host_camera_create", "prt_host_bvh_build", "prt_host_free",
 ]
 
@@ -175,6 +175,8 @@ def lib():
     L.prt_host_scene_set_env_light.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.prt_host_scene_set_env_light.restype = None
     L.prt_host_scene_load_env_light.argtypes = [vp, C.c_char_p]
+    L.prt_host_save_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.prt_host_save_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.prt_host_scene_describe.argtypes = [vp]
     L.prt_host_scene_describe.restype = C.POINTER(SceneDesc)
     L.prt_host_scene_bbox.argtypes = [vp, f32p]
@@ -502,6 +504,18 @@ def owned_pixel_mask(width, height, rank, nranks, tile=16):
     ty, tx = np.meshgrid(np.arange(height) // tile, np.arange(width) // tile, indexing="ij")
     tiles_x = (width + tile - 1) // tile
     return ((ty * tiles_x + tx) % nranks) == rank
+
+
+def save_exr(path, rgb):
+    """Image::saveExr (image.cpp:82-139): (H, W, 3) float image -> half-float OpenEXR with channels B, G, R."""
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    _check(lib().prt_host_save_exr(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)), "prt_host_save_exr")
+
+
+def save_ppm(path, rgb, tonemap=True):
+    """Image::savePpm (image.cpp:52-80): c/(c+1) tone map (optional), clamp, gamma 1/2.2, 8 bits."""
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    _check(lib().prt_host_save_ppm(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p), int(tonemap)), "prt_host_save_ppm")
 
 
 def gather_contexts(tracers, x0, y0, x1, y1):

@@ -404,11 +404,83 @@ void Image::savePfm(const char* path) const
     printf("Save %s\n", path);
 }
 
+// float -> IEEE half, round to nearest even; overflow to infinity, NaN kept a NaN
+static uint16_t floatToHalf(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u | ((x >> 13) & 0x3ffu) : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); // rounds to 2^16 or beyond
+    if (x < 0x33000001u) return (uint16_t)sign;               // below half of the smallest subnormal (ties to even -> 0)
+    uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u;
+    if (e < 113) { // half subnormal: shift the 24-bit significand down to 10 bits at exponent -14
+        const uint32_t shift = 126 - e; // 14..24
+        uint32_t h = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((e - 112) << 10) | ((m >> 13) & 0x3ffu), rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++; // may carry into the exponent: still the right value
+    return (uint16_t)(sign | h);
+}
+
+// image.cpp:82-139: three half-float channels named B, G, R (the reference converts float -> half through tinyexr).  Written
+// here directly as an uncompressed scan-line OpenEXR 2.0 file: magic, version, header attributes, line offset table, one
+// block per scan line with the channels in name order.
 void Image::saveExr(const char* path) const
 {
-    // image.cpp:82-139 writes half-float EXR through tinyexr (not vendored).  Raw float PFM keeps full precision.
-    std::string p = std::string(path) + ".pfm";
-    savePfm(p.c_str());
+    FILE* fp = fopen(path, "wb");
+    if (!fp) {
+        printf("Error saving %s\n", path);
+        return;
+    }
+    std::vector<uint8_t> hd;
+    auto put = [&](const void* p, size_t n) { hd.insert(hd.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+    auto putStr = [&](const char* t) { put(t, strlen(t) + 1); };
+    auto putI = [&](int32_t v) { put(&v, 4); };
+    auto putF = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char* name, const char* type, int32_t size) { putStr(name); putStr(type); putI(size); };
+    putI(20000630);
+    putI(2);
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char* c : {"B", "G", "R"}) {
+        putStr(c);
+        putI(1); // HALF
+        const uint8_t linear[4] = {0, 0, 0, 0};
+        put(linear, 4);
+        putI(1);
+        putI(1);
+    }
+    hd.push_back(0);
+    attr("compression", "compression", 1); hd.push_back(0); // NO_COMPRESSION
+    attr("dataWindow", "box2i", 16); putI(0); putI(0); putI((int32_t)m_width - 1); putI((int32_t)m_height - 1);
+    attr("displayWindow", "box2i", 16); putI(0); putI(0); putI((int32_t)m_width - 1); putI((int32_t)m_height - 1);
+    attr("lineOrder", "lineOrder", 1); hd.push_back(0); // increasing y
+    attr("pixelAspectRatio", "float", 4); putF(1.0f);
+    attr("screenWindowCenter", "v2f", 8); putF(0.0f); putF(0.0f);
+    attr("screenWindowWidth", "float", 4); putF(1.0f);
+    hd.push_back(0);
+    const uint64_t lineBytes = 8 + (uint64_t)m_width * 3 * 2;
+    uint64_t offset = hd.size() + (uint64_t)m_height * 8;
+    for (uint32_t y = 0; y < m_height; y++, offset += lineBytes) put(&offset, 8);
+    fwrite(hd.data(), 1, hd.size(), fp);
+    std::vector<uint16_t> line((size_t)m_width * 3);
+    for (uint32_t y = 0; y < m_height; y++) {
+        const float* px = &m_pixels[(size_t)y * m_width * 3];
+        for (uint32_t x = 0; x < m_width; x++) {
+            line[x] = floatToHalf(px[3 * x + 2]);                       // B
+            line[(size_t)m_width + x] = floatToHalf(px[3 * x + 1]);     // G
+            line[(size_t)2 * m_width + x] = floatToHalf(px[3 * x + 0]); // R
+        }
+        const int32_t yy = (int32_t)y, size = (int32_t)(line.size() * 2);
+        fwrite(&yy, 4, 1, fp);
+        fwrite(&size, 4, 1, fp);
+        fwrite(line.data(), 2, line.size(), fp);
+    }
+    fclose(fp);
+    printf("Saved %s\n", path);
 }
 
 // ---------------------------------------------------------------- thread pool (thread_pool.cpp)

@@ -325,3 +325,52 @@ def test_obj_mtl_reader_decodes_png_maps(L, tmp_path, level, strategy):
         sc.add(prt_amd.Mesh.load_obj(str(tmp_path / "n.obj")))
         b = sc.arrays()
         assert np.array_equal(b["textures"][0], want), name
+
+
+def test_exr_and_ppm_writers(L, tmp_path):
+    """Image::saveExr (image.cpp:82-139): half-float B, G, R planes -- written here as an uncompressed scan-line OpenEXR;
+    parsed back, every sample must be the round-to-nearest-even half of the float.  Image::savePpm (image.cpp:52-80)."""
+    import struct
+    rng = np.random.default_rng(9)
+    h, w = 7, 13
+    img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+    specials = np.array([0.0, -0.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, 6.0975552e-5, 65504.0, 65519.9, 65520.0, 1e9, np.inf, -np.inf,
+                         np.nan, 1.0009765625, 1.00048828125, 1.00146484375, 0.33333334, -2.5, 1023.75, 2047.5, 2048.5], dtype=np.float32)
+    img.reshape(-1)[:len(specials)] = specials
+    p = tmp_path / "o.exr"
+    prt_amd.save_exr(str(p), img)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<ii", raw, 0) == (20000630, 2)
+    o, attrs = 8, {}
+    while raw[o] != 0:
+        e = raw.index(b"\0", o); name = raw[o:e].decode(); o = e + 1
+        e = raw.index(b"\0", o); typ = raw[o:e].decode(); o = e + 1
+        (size,) = struct.unpack_from("<i", raw, o); o += 4
+        attrs[name] = (typ, raw[o:o + size]); o += size
+    o += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"][1] == b"\0"
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1)
+    ch = attrs["channels"][1]
+    assert [ch[i * 18:i * 18 + 1] for i in range(3)] == [b"B", b"G", b"R"] and struct.unpack_from("<i", ch, 2)[0] == 1  # HALF
+    offs = struct.unpack_from(f"<{h}Q", raw, o)
+    with np.errstate(over="ignore"):
+        want = img.astype(np.float16)
+    for y in range(h):
+        yy, size = struct.unpack_from("<ii", raw, offs[y])
+        assert (yy, size) == (y, w * 3 * 2)
+        line = np.frombuffer(raw, dtype="<u2", count=w * 3, offset=offs[y] + 8).reshape(3, w)
+        for k, c in enumerate((2, 1, 0)):  # B, G, R
+            got, exp = line[k], want[y, :, c].view(np.uint16)
+            nan = np.isnan(want[y, :, c])
+            assert np.array_equal(got[~nan], exp[~nan]), (y, c)
+            assert ((got[nan] & 0x7c00) == 0x7c00).all() and ((got[nan] & 0x3ff) != 0).all()
+    # PPM: c/(c+1), clamp, pow(1/2.2), * 255, truncate
+    q = tmp_path / "o.ppm"
+    fin = np.nan_to_num(img, nan=0.0, posinf=1e30, neginf=0.0)
+    prt_amd.save_ppm(str(q), fin, tonemap=True)
+    data = open(q, "rb").read()
+    assert data.startswith(b"P6\n%d %d\n255\n" % (w, h))
+    px = np.frombuffer(data[-w * h * 3:], dtype=np.uint8).reshape(h, w, 3)
+    c = fin.astype(np.float64)
+    ref = np.clip(c / (c + 1.0), 0.0, 1.0) ** (1.0 / 2.2) * 255.0
+    assert (np.abs(px.astype(np.float64) - np.floor(ref)) <= 1).all()
