@@ -5,12 +5,15 @@
 // caller; the one deliberate difference is that the image is handed to the GPU in ONE TraceBlock call instead of one
 // call per 16x16 tile from a thread pool (both work; per-tile calls pay a launch + download each).
 //
-//   ./prt_main [cornell|bunny|atrium] [width height spp]      (needs an MI355X; there is no CPU path)
+//   ./prt_main [cornell|bunny|atrium] [width height spp [tiles]]      (needs an MI355X; there is no CPU path)
+//   `tiles` drives the image the way the reference's main.cpp does: one TraceBlock per 16x16 tile from a thread pool
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
+#include <mutex>
 
 #include "../prt_amd/csrc/host/prt.h"
 
@@ -91,12 +94,38 @@ int main(int argc, char** argv)
     Image image(width, height, true, exposure);
     auto start = std::chrono::steady_clock::now();
     PathTracer tracer;
-    tracer.TraceBlock(image, 0, 0, width - 1, height - 1, scene, camera, kSamples);
+    Stats st;
+    st.clear();
+    double kernelMs = 0.0;
+    if (argc > 5 && !strcmp(argv[5], "tiles")) {
+        // the reference's own loop (main.cpp:121-176): one task per 16x16 tile on the thread pool, a PathTracer per task
+        ThreadPool threadPool;
+        threadPool.create(8);
+        std::mutex statsMutex;
+        const uint32_t kTile = 16;
+        for (uint32_t y = 0; y < height; y += kTile) {
+            auto y0 = y, y1 = std::min(y + kTile, height - 1);
+            for (uint32_t x = 0; x < width; x += kTile) {
+                auto x0 = x, x1 = std::min(x + kTile, width - 1);
+                threadPool.queue([&image, x0, y0, x1, y1, &scene, &camera, &st, &statsMutex, &kernelMs, kSamples]() {
+                    PathTracer t;
+                    t.TraceBlock(image, x0, y0, x1, y1, scene, camera, kSamples);
+                    std::lock_guard<std::mutex> g(statsMutex);
+                    st.merge(t.getStats());
+                    kernelMs += t.getKernelMs();
+                });
+            }
+        }
+        threadPool.waitAllTasksDone();
+    } else {
+        tracer.TraceBlock(image, 0, 0, width - 1, height - 1, scene, camera, kSamples);
+        st = tracer.getStats();
+        kernelMs = tracer.getKernelMs();
+    }
     auto end = std::chrono::steady_clock::now();
     auto ms = (float)std::chrono::duration_cast<std::chrono::milliseconds>(end - start).count();
-    auto st = tracer.getStats();
     printf("%.3fms @%uspp, %llu rays (%llu occlusion), kernels %.3f ms => %.1f Mray/s\n", ms, kSamples, (unsigned long long)st.raysTraced,
-           (unsigned long long)st.occludedTraced, tracer.getKernelMs(), st.raysTraced / tracer.getKernelMs() / 1e3);
+           (unsigned long long)st.occludedTraced, kernelMs, st.raysTraced / kernelMs / 1e3);
     image.saveExr("render.exr");  // main.cpp:189
     image.savePfm("render.pfm");  // the same pixels as raw floats
     image.savePpm("render.ppm");

@@ -553,6 +553,15 @@ struct DeviceSlot {
     uint64_t sceneRevision = 0;
     prt_camera_desc camera{};
     bool haveCamera = false;
+    // The reference's main.cpp calls TraceBlock once per 16x16 tile from a thread pool (main.cpp:132-160).  A launch per tile
+    // would pay the whole pipeline's fixed cost 8160 times for a 1080p image, so the second rectangle asked for with the
+    // same scene, camera and settings renders the WHOLE image once; that and every later rectangle is served from the
+    // kept frame (pixels do not depend on how the image is cut: per-pixel generator states).
+    prt_render_params frameParams{};
+    bool haveFrameParams = false, frameValid = false;
+    uint32_t rectCalls = 0;
+    std::vector<float> frame;
+    prt_hip_stats firstRectStats{};
 };
 std::mutex g_deviceMutex;
 std::map<int, DeviceSlot> g_devices;
@@ -577,7 +586,8 @@ void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1,
     std::lock_guard<std::mutex> g(g_deviceMutex); // calls on one context are serialised (prt_hip.h)
     DeviceSlot& slot = g_devices[m_options.device];
     if (!slot.ctx && prt_hip_create(m_options.device, &slot.ctx) != PRT_HIP_OK) die("prt_hip_create");
-    if (slot.scene != &scene || slot.sceneRevision != scene.getRevision()) {
+    const bool sceneChanged = slot.scene != &scene || slot.sceneRevision != scene.getRevision();
+    if (sceneChanged) {
         prt_scene_desc desc;
         Scene::DescStorage store;
         scene.describe(desc, store);
@@ -587,7 +597,8 @@ void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1,
     }
     prt_camera_desc cd;
     camera.describe(cd);
-    if (!slot.haveCamera || memcmp(&cd, &slot.camera, sizeof(cd)) != 0) {
+    const bool cameraChanged = !slot.haveCamera || memcmp(&cd, &slot.camera, sizeof(cd)) != 0;
+    if (cameraChanged) {
         if (prt_hip_set_camera(slot.ctx, &cd) != PRT_HIP_OK) die("prt_hip_set_camera");
         slot.camera = cd;
         slot.haveCamera = true;
@@ -601,10 +612,42 @@ void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1,
     p.tileSize = 16; // main.cpp:123-124
     p.rank = 0;
     p.nranks = 1;
-    if (prt_hip_render(slot.ctx, x0, y0, x1, y1, &p, nullptr, nullptr) != PRT_HIP_OK) die("prt_hip_render");
-    if (prt_hip_download(slot.ctx, image.getPixels(), x0, y0, x1, y1) != PRT_HIP_OK) die("prt_hip_download");
+    const uint32_t W = cd.width, H = cd.height;
+    if (sceneChanged || cameraChanged || !slot.haveFrameParams || memcmp(&p, &slot.frameParams, sizeof(p)) != 0) {
+        slot.frameParams = p;
+        slot.haveFrameParams = true;
+        slot.frameValid = false;
+        slot.rectCalls = 0;
+    }
+    auto copyRect = [&]() {
+        const size_t row = (size_t)(x1 - x0 + 1) * 3 * sizeof(float);
+        for (uint32_t y = y0; y <= y1; y++)
+            memcpy(image.getPixels() + ((size_t)y * W + x0) * 3, &slot.frame[((size_t)y * W + x0) * 3], row);
+    };
+    if (x1 < x0 || y1 < y0 || x1 >= W || y1 >= H) die("TraceBlock: rectangle outside the image");
+    if (slot.frameValid) { // a tile of a frame that has been rendered already: its rays were counted then
+        copyRect();
+        return;
+    }
+    const bool whole = (x0 == 0 && y0 == 0 && x1 == W - 1 && y1 == H - 1);
+    const bool wholeNow = !whole && ++slot.rectCalls >= 2;
+    const uint32_t rx0 = wholeNow ? 0 : x0, ry0 = wholeNow ? 0 : y0, rx1 = wholeNow ? W - 1 : x1, ry1 = wholeNow ? H - 1 : y1;
+    if (prt_hip_render(slot.ctx, rx0, ry0, rx1, ry1, &p, nullptr, nullptr) != PRT_HIP_OK) die("prt_hip_render");
     prt_hip_stats st;
-    if (prt_hip_get_stats(slot.ctx, &st) != PRT_HIP_OK) die("prt_hip_get_stats");
+    if (wholeNow) {
+        slot.frame.assign((size_t)W * H * 3, 0.0f);
+        if (prt_hip_download(slot.ctx, slot.frame.data(), 0, 0, W - 1, H - 1) != PRT_HIP_OK) die("prt_hip_download");
+        if (prt_hip_get_stats(slot.ctx, &st) != PRT_HIP_OK) die("prt_hip_get_stats");
+        slot.frameValid = true;
+        copyRect();
+        // the first rectangle was rendered (and counted) on its own before: the frame's totals minus that share
+        st.raysTraced -= slot.firstRectStats.raysTraced;
+        st.occludedTraced -= slot.firstRectStats.occludedTraced;
+    } else {
+        if (prt_hip_download(slot.ctx, image.getPixels(), x0, y0, x1, y1) != PRT_HIP_OK) die("prt_hip_download");
+        if (prt_hip_get_stats(slot.ctx, &st) != PRT_HIP_OK) die("prt_hip_get_stats");
+        if (!whole) slot.firstRectStats = st;
+    }
     m_stats.raysTraced += st.raysTraced;
     m_stats.occludedTraced += st.occludedTraced;
     m_kernelMs += st.kernelMs;

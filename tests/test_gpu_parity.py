@@ -591,3 +591,13 @@ def test_cpp_drop_in_driver_matches_python_host(tracer, tmp_path):
     assert (w, h) == (W, H)
     assert_bits_equal(np.ascontiguousarray(img), ref, "C++ driver vs Python host")
     assert f"{tracer.last_stats['raysTraced']} rays" in out.stdout
+    # the reference's own calling pattern: one TraceBlock per 16x16 tile from a thread pool, a PathTracer per task
+    # (main.cpp:132-160).  The second tile renders the whole frame once; all tiles come out of it; totals are the frame's.
+    out2 = subprocess.run([os.path.join(ex, "prt_main"), "bunny", str(W), str(H), str(spp), "tiles"], cwd=tmp_path, capture_output=True, text=True,
+                          timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    with open(tmp_path / "render.pfm", "rb") as f:
+        f.readline(); f.readline(); f.readline()
+        img2 = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
+    assert_bits_equal(np.ascontiguousarray(img2), ref, "C++ driver, per-tile calls")
+    assert f"{tracer.last_stats['raysTraced']} rays" in out2.stdout
