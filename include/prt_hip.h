@@ -157,6 +157,11 @@ int prt_hip_set_camera(prt_hip_ctx* ctx, const prt_camera_desc* camera);
  * prt_hip_get_stats synchronise. ---- */
 int prt_hip_render(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                    const prt_render_params* params, float* d_rgb, void* stream);
+/* GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): one jittered camera ray per pixel, the surface's diffuse colour
+ * (type 0 = kDiffuse) or bump-mapped normal * 0.5 + 0.5 (1 = kMeshNormal, 2 = kNormal), times exposure.  Same rectangle,
+ * framebuffer and stream conventions as prt_hip_render; the pixel's generator state is the same function of (x, y, seed). */
+int prt_hip_render_gbuffer(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t type, uint32_t seed,
+                           float exposure, float* d_rgb, void* stream);
 /* copies the rectangle (inclusive) of the context's framebuffer into a host image of the camera's size */
 int prt_hip_download(prt_hip_ctx* ctx, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 float* prt_hip_framebuffer(prt_hip_ctx* ctx); /* device pointer, width*height*3 floats */

@@ -1401,6 +1401,42 @@ void orc_camera_packet(const orc_camera* cam, uint32_t* rng, uint32_t x, uint32_
     camera_packet(cam, rng, x, y, org, dir, avgDir, NULL);
 }
 
+/* ------------------------------------------------------------------ GbufferVisualizer, gbuffer_visualizer.cpp:17-51
+ * One jittered single ray per pixel (Camera::GenerateJitteredRay, camera.cpp:12-33: two generateMinus1to1 draws), nearest
+ * hit by the single-ray traversal, then the surface's diffuse colour (type 0) or its bump-mapped normal * 0.5 + 0.5 (types 1
+ * and 2 -- the reference gives kMeshNormal and kNormal the same expression).  Per-pixel generator state as for the path tracer. */
+void orc_gbuffer_block(const orc_scene* scene, const orc_camera* cam, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t type,
+                       uint32_t seed, float exposure, float* rgb)
+{
+    const float kScreenScale = 0.6f;
+    const float kAspect = (float)cam->width / (float)cam->height;
+    const float kScaleX = 0.5f * cam->invWidth;
+    const float kScaleY = 0.5f * cam->invHeight;
+    v3 right = ld3(cam->right), up = ld3(cam->up), fwd = ld3(cam->dir);
+    for (uint32_t y = y0; y <= y1; y++) {
+        for (uint32_t x = x0; x <= x1; x++) {
+            uint32_t rng = orc_pixel_seed(x, y, cam->width, seed);
+            float dx = rng_pm1(&rng, NULL) * kScaleX;
+            float dy = rng_pm1(&rng, NULL) * kScaleY;
+            float nx = 2.0f * ((float)x * cam->invWidth - 0.5f + dx) * kScreenScale * kAspect;
+            float ny = -2.0f * ((float)y * cam->invHeight - 0.5f + dy) * kScreenScale;
+            v3 d = normalize3(add3(add3(scale3(nx, right), scale3(ny, up)), fwd));
+            float dir[3];
+            st3(dir, d);
+            orc_hit hit;
+            orc_intersect_single(scene, cam->pos, dir, 100000.0f, &hit, NULL);
+            v3 color = v3s(0.0f);
+            if (hit.t != -1.0f) {
+                surf_t prop;
+                get_surface(scene, &prop, &hit, NULL);
+                if (type == 0) color = sample_diffuse(scene, prop.material, prop.uv, NULL);
+                else color = add3(scale3(0.5f, sample_bump(scene, prop.material, &prop, NULL)), v3s(0.5f));
+            }
+            st3(rgb + ((size_t)x + (size_t)y * cam->width) * 3, scale3(exposure, color)); /* image.cpp:45 */
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ path_tracer.cpp:77-308 */
 static v3 diffuse_dir(v3 normal, float r2, float r1) /* :143-153 / :176-184 */
 {

@@ -153,6 +153,9 @@ void orc_render(const orc_scene*, const orc_camera*, uint32_t samples, uint32_t 
 /* the same over an inclusive pixel rectangle (used for the bounded CPU-baseline sample of bench.py) */
 void orc_render_rect(const orc_scene*, const orc_camera*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t samples,
                      uint32_t maxDepth, uint32_t seed, float exposure, int threads, float* rgb, orc_stats* st);
+/* GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51); type 0 = kDiffuse, 1 = kMeshNormal, 2 = kNormal */
+void orc_gbuffer_block(const orc_scene*, const orc_camera*, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t type,
+                       uint32_t seed, float exposure, float* rgb);
 int orc_max_threads(void);
 void orc_set_rr_depth(uint32_t rrDepth); /* default 4 = the reference (path_tracer.cpp:258) */
 

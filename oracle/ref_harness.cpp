@@ -59,6 +59,7 @@
 #ifdef REF_WITH_GLUE
 #include "image.h"
 #include "path_tracer.h"
+#include "gbuffer_visualizer.h"
 #include "sample_models.h"
 #endif
 #undef private
@@ -521,6 +522,30 @@ static int cmdRender(const char* scenePath, uint32_t spp, uint32_t x0, uint32_t 
     return 0;
 }
 
+// ------------------------------------------------------------------ GbufferVisualizer::TraceBlock per pixel (gbuffer_visualizer.cpp:17-51)
+// out: f32 rgb of the rectangle, row-major
+static int cmdGbuffer(const char* scenePath, int type, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t seed, const char* out)
+{
+    FScene fs = loadScene(scenePath);
+    RefScene r = buildRef(fs);
+    refGlueRegister(r.bvhs, r.omeshes);
+    const uint32_t W = fs.width, H = fs.height;
+    Image* image = refGlueMakeImage(W, H, fs.exposure);
+    for (uint32_t y = y0; y <= y1; y++)
+        for (uint32_t x = x0; x <= x1; x++) {
+            GbufferVisualizer vis((GbufferVisualizer::Type)type);
+            vis.m_rand.m_state.a = orc_pixel_seed(x, y, W, seed); // the visualiser's generator, per pixel like the path tracer's
+            vis.TraceBlock(*image, x, y, x, y, *r.scene, r.camera);
+        }
+    const uint32_t rw = x1 - x0 + 1, rh = y1 - y0 + 1;
+    std::vector<float> o((size_t)rw * rh * 3);
+    const float* px = refGlueImagePixels(image);
+    for (uint32_t y = 0; y < rh; y++) memcpy(&o[(size_t)y * rw * 3], &px[((size_t)(y0 + y) * W + x0) * 3], (size_t)rw * 12);
+    writeAll(out, o.data(), o.size() * 4);
+    (void)H;
+    return 0;
+}
+
 // ------------------------------------------------------------------ InfiniteAreaLight::create + sample (light.cpp:30-128)
 // in: env file (see ref_glue.cpp Texture::loadExr), u file = f32 pairs (u.x, u.y)
 // out: i32 width, i32 height, f32 verticalP[height], f32 horizontalP[width*height], then per pair f32 dir[3], color[3]
@@ -589,6 +614,9 @@ int main(int argc, char** argv)
         return cmdRender(argv[2], (uint32_t)atoi(argv[3]), (uint32_t)atoi(argv[4]), (uint32_t)atoi(argv[5]), (uint32_t)atoi(argv[6]),
                          (uint32_t)atoi(argv[7]), (uint32_t)strtoul(argv[8], 0, 10), atoi(argv[9]), argv[10], argc >= 12 ? argv[11] : nullptr);
     if (argc >= 5 && !strcmp(argv[1], "envlight")) return cmdEnvLight(argv[2], argv[3], argv[4]);
+    if (argc >= 10 && !strcmp(argv[1], "gbuffer"))
+        return cmdGbuffer(argv[2], atoi(argv[3]), (uint32_t)atoi(argv[4]), (uint32_t)atoi(argv[5]), (uint32_t)atoi(argv[6]), (uint32_t)atoi(argv[7]),
+                          (uint32_t)strtoul(argv[8], 0, 10), argv[9]);
     if (argc >= 3 && !strcmp(argv[1], "cornell")) return cmdCornell(argv[2]);
 #endif
     fprintf(stderr,

@@ -103,7 +103,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 # every symbol include/prt_hip.h and include/prt_host.h declare
 EXPORTS = [
     "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
-    "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
+    "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_render_gbuffer", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
     "prt_hip_get_stats", "prt_hip_trace_rays", "prt_hip_test_leaf", "prt_hip_test_sincos", "prt_hip_test_powf",
     "prt_hip_test_camera",
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
@@ -140,6 +140,7 @@ def lib():
     L.prt_hip_set_camera.argtypes = [vp, C.POINTER(CameraDesc)]
     L.prt_hip_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RenderParams), vp, vp]
     L.prt_hip_download.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.prt_hip_render_gbuffer.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, vp, vp]
     L.prt_hip_gather.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.prt_hip_framebuffer.restype = vp
     L.prt_hip_framebuffer.argtypes = [vp]
@@ -398,6 +399,16 @@ class PathTracer:
         img = np.zeros((H, W, 3), dtype=np.float32)
         _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
         self.last_stats = self.stats()  # raises on stack overflow
+        return img[y0:y1 + 1, x0:x1 + 1].copy()
+
+    def gbuffer(self, kind, x0=0, y0=0, x1=None, y1=None, exposure=1.0):
+        """GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): kind 0 diffuse colour, 1 / 2 bump-mapped normal."""
+        W, H = self._camera.width, self._camera.height
+        x1 = W - 1 if x1 is None else x1
+        y1 = H - 1 if y1 is None else y1
+        _check(lib().prt_hip_render_gbuffer(self._ctx, x0, y0, x1, y1, kind, self.seed, exposure, None, None), "prt_hip_render_gbuffer")
+        img = np.zeros((H, W, 3), dtype=np.float32)
+        _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
         return img[y0:y1 + 1, x0:x1 + 1].copy()
 
     def render(self, samples, **kw):

@@ -269,6 +269,20 @@ private:
     float m_exposure;
 };
 
+// ---- gbuffer_visualizer.h:15-35: the debug integrator (surface colour / normal per pixel), on the same kernels ----
+class GbufferVisualizer
+{
+public:
+    enum class Type { kDiffuse, kMeshNormal, kNormal };
+    GbufferVisualizer(Type type = Type::kDiffuse, uint32_t seed = 12345, int device = 0) : m_type(type), m_seed(seed), m_device(device) {}
+    void TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const Scene& scene, const Camera& camera);
+
+private:
+    Type m_type;
+    uint32_t m_seed; // per-pixel generator states, replaces m_rand (gbuffer_visualizer.h:33)
+    int m_device;
+};
+
 // ---- stats.h:10-33 ----
 struct Stats {
     uint64_t nodesTraversed, primsTraversed, raysTraced, occludedTraced, triTested;

@@ -580,13 +580,12 @@ void PathTracer::releaseDevice()
     g_devices.clear();
 }
 
-void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const Scene& scene, const Camera& camera,
-                            uint32_t samples)
+// The device's context with this scene and camera on it (uploaded again only when they changed).  Caller holds g_deviceMutex.
+static DeviceSlot& readySlot(int device, const Scene& scene, const Camera& camera, prt_camera_desc& cd, bool& sceneChanged, bool& cameraChanged)
 {
-    std::lock_guard<std::mutex> g(g_deviceMutex); // calls on one context are serialised (prt_hip.h)
-    DeviceSlot& slot = g_devices[m_options.device];
-    if (!slot.ctx && prt_hip_create(m_options.device, &slot.ctx) != PRT_HIP_OK) die("prt_hip_create");
-    const bool sceneChanged = slot.scene != &scene || slot.sceneRevision != scene.getRevision();
+    DeviceSlot& slot = g_devices[device];
+    if (!slot.ctx && prt_hip_create(device, &slot.ctx) != PRT_HIP_OK) die("prt_hip_create");
+    sceneChanged = slot.scene != &scene || slot.sceneRevision != scene.getRevision();
     if (sceneChanged) {
         prt_scene_desc desc;
         Scene::DescStorage store;
@@ -595,14 +594,38 @@ void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1,
         slot.scene = &scene;
         slot.sceneRevision = scene.getRevision();
     }
-    prt_camera_desc cd;
     camera.describe(cd);
-    const bool cameraChanged = !slot.haveCamera || memcmp(&cd, &slot.camera, sizeof(cd)) != 0;
+    cameraChanged = !slot.haveCamera || memcmp(&cd, &slot.camera, sizeof(cd)) != 0;
     if (cameraChanged) {
         if (prt_hip_set_camera(slot.ctx, &cd) != PRT_HIP_OK) die("prt_hip_set_camera");
         slot.camera = cd;
         slot.haveCamera = true;
     }
+    if (sceneChanged || cameraChanged) slot.frameValid = false;
+    return slot;
+}
+
+// gbuffer_visualizer.cpp:17-26
+void GbufferVisualizer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const Scene& scene, const Camera& camera)
+{
+    std::lock_guard<std::mutex> g(g_deviceMutex);
+    prt_camera_desc cd;
+    bool sceneChanged, cameraChanged;
+    DeviceSlot& slot = readySlot(m_device, scene, camera, cd, sceneChanged, cameraChanged);
+    if (prt_hip_render_gbuffer(slot.ctx, x0, y0, x1, y1, (uint32_t)m_type, m_seed, image.getExposure(), nullptr, nullptr) != PRT_HIP_OK)
+        die("prt_hip_render_gbuffer");
+    if (prt_hip_download(slot.ctx, image.getPixels(), x0, y0, x1, y1) != PRT_HIP_OK) die("prt_hip_download");
+    slot.frameValid = false; // the context's framebuffer no longer holds a path-traced frame
+    slot.haveFrameParams = false;
+}
+
+void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const Scene& scene, const Camera& camera,
+                            uint32_t samples)
+{
+    std::lock_guard<std::mutex> g(g_deviceMutex); // calls on one context are serialised (prt_hip.h)
+    prt_camera_desc cd;
+    bool sceneChanged, cameraChanged;
+    DeviceSlot& slot = readySlot(m_options.device, scene, camera, cd, sceneChanged, cameraChanged);
     prt_render_params p{};
     p.samples = samples;
     p.maxDepth = m_options.maxDepth;

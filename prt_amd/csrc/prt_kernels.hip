@@ -777,6 +777,68 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     if (overflow) atomicAdd(&C[7], 1ull);
 }
 
+// ============================================================================ G-buffer visualiser
+// GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): per pixel ONE jittered single ray (Camera::GenerateJitteredRay,
+// camera.cpp:12-33: two generateMinus1to1 draws from the pixel's generator), the single-ray nearest traversal, then the
+// surface's diffuse colour (type 0) or bump-mapped normal * 0.5 + 0.5 (types 1, 2).  Same persistent wave loop as the trace
+// kernels; the ray source makes the camera ray, the hit sink shades and writes the pixel (Image::writePixel, image.cpp:44-50).
+struct GbufArgs {
+    DevScene sc;
+    DevCamera cam;
+    uint32_t x0, y0, rw, rh, type, seed;
+    float exposure;
+    float* rgb;
+    uint32_t* cursor;
+    uint32_t* spill;
+    uint32_t spillStride;
+    unsigned long long* counters;
+};
+
+struct GbufSrc {
+    const GbufArgs* A;
+    __device__ __forceinline__ uint32_t count() const { return A->rw * A->rh; }
+    __device__ __forceinline__ uint32_t* cursor() const { return A->cursor; }
+    __device__ __forceinline__ void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev) const
+    {
+        const uint32_t x = A->x0 + i % A->rw, y = A->y0 + i / A->rw;
+        const uint32_t s1 = xorshift32(pixel_seed(x, y, A->cam.width, A->seed)), s2 = xorshift32(s1);
+        org = mk3(A->cam.pos[0], A->cam.pos[1], A->cam.pos[2]);
+        dir = camera_dir(A->cam, x, y, s1, s2);
+        maxT = 100000.0f; // camera.cpp:26
+        rev = 0;
+    }
+    __device__ __forceinline__ void store_hit(uint32_t i, const DevHit& h) const
+    {
+        const uint32_t x = A->x0 + i % A->rw, y = A->y0 + i / A->rw;
+        Vec3 color = mk3(0.0f, 0.0f, 0.0f);
+        if (h.t != -1.0f) {
+            Traffic tr{0, 0, 0, 0};
+            Surface s;
+            get_surface<false>(A->sc, h, s, tr);
+            if (A->type == 0u) color = sample_diffuse<false>(A->sc, s.mat, s.uv, tr);
+            else color = add3(scale3(0.5f, sample_bump<false>(A->sc, s.mat, s, tr)), mk3(0.5f, 0.5f, 0.5f));
+        }
+        float* px = A->rgb + ((size_t)x + (size_t)y * A->cam.width) * 3;
+        px[0] = A->exposure * color.x;
+        px[1] = A->exposure * color.y;
+        px[2] = A->exposure * color.z;
+    }
+    __device__ __forceinline__ void store_occ(uint32_t, bool) const {}
+};
+
+__global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
+{
+    __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ float ldsT[PRT_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    GbufSrc src{&A};
+    Traffic tr{0, 0, 0, 0};
+    uint32_t overflow = 0;
+    trace_loop<PRT_MODE_SINGLE, false>(A.sc, src, st, tr, overflow);
+    if (overflow) atomicAdd(&A.counters[7], 1ull);
+}
+
 // ============================================================================ row-level test kernels
 struct RaysArgs {
     DevScene sc;
@@ -1561,6 +1623,51 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
     }
     c->timed = true;
+    return PRT_HIP_OK;
+}
+
+int prt_hip_render_gbuffer(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t type, uint32_t seed, float exposure,
+                           float* d_rgb, void* stream)
+{
+    if (!c) return fail(PRT_HIP_EINVAL, "NULL argument");
+    if (!c->haveScene || !c->haveCamera) return fail(PRT_HIP_ESTATE, "upload a scene and set a camera first");
+    const uint32_t W = c->cam.width, H = c->cam.height;
+    if (x1 < x0 || y1 < y0 || x1 >= W || y1 >= H) return fail(PRT_HIP_EINVAL, "pixel rectangle outside the image");
+    if (type > 2) return fail(PRT_HIP_EINVAL, "type must be 0 (diffuse), 1 (mesh normal) or 2 (normal)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    hipStream_t caller = (stream && (hipStream_t)stream != c->stream) ? (hipStream_t)stream : nullptr;
+    if (caller) {
+        HIP_TRY(hipEventRecord(c->evIn, caller));
+        HIP_TRY(hipStreamWaitEvent(s, c->evIn, 0));
+    }
+    if (!d_rgb) {
+        if (c->fbPixels != (size_t)W * H) {
+            if (c->fb) (void)hipFree(c->fb);
+            c->fb = nullptr;
+            HIP_TRY(hipMalloc(&c->fb, (size_t)W * H * 3 * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(c->fb, 0, (size_t)W * H * 3 * sizeof(float), s));
+            c->fbPixels = (size_t)W * H;
+        }
+        d_rgb = c->fb;
+    }
+    const uint32_t rw = x1 - x0 + 1, rh = y1 - y0 + 1;
+    if ((uint64_t)rw * rh > 0xffffffffull) return fail(PRT_HIP_EINVAL, "rectangle too large");
+    const uint32_t want = (uint32_t)(((uint64_t)rw * rh + PRT_BLOCK - 1) / PRT_BLOCK);
+    const uint32_t blocks = std::min<uint32_t>(want, (uint32_t)persistent_blocks(c));
+    int rc = ensure_launch_resources(c, (uint32_t)persistent_blocks(c));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), s));
+    GbufArgs A{c->sc, c->cam, x0, y0, rw, rh, type, seed, exposure, d_rgb, c->work, c->spill, c->spillThreads, c->counters};
+    hipLaunchKernelGGL(gbuffer_kernel, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("gbuffer_kernel launch: ") + hipGetErrorString(le));
+    if (caller) {
+        HIP_TRY(hipEventRecord(c->evOut, s));
+        HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
+    }
+    c->timed = false;
     return PRT_HIP_OK;
 }
 

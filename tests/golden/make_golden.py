@@ -238,6 +238,16 @@ def dump_env_light():
                         rays=np.array([st["raysTraced"], st["occludedTraced"]], dtype=np.uint64), **out)
 
 
+def dump_gbuffer():
+    # GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51, Camera::GenerateJitteredRay camera.cpp:12-33) of the compiled
+    # reference on Cornell + teapot: diffuse colour and bump-mapped normal images
+    desc = T.cornell_scene(96, 96, with_teapot=True)
+    rect = (8, 8, 87, 87)
+    out = {f"kind{k}": T.ref_gbuffer(desc, k, rect) for k in (0, 1, 2)}
+    np.savez_compressed(os.path.join(HERE, "gbuffer.npz"), rect=np.array(rect), **out)
+    print("gbuffer means", {k: float(v.mean()) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", T.ORACLE_DIR])
     dump_cornell()
@@ -246,3 +256,4 @@ if __name__ == "__main__":
     dump_scene_vectors()
     dump_radiance()
     dump_env_light()
+    dump_gbuffer()

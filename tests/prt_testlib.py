@@ -135,6 +135,8 @@ def oracle():
     L.orc_scene_set_env_light.restype = None
     L.orc_x_env_sample.argtypes = [vp, C.c_uint32, vp, vp, vp]
     L.orc_x_env_sample.restype = None
+    L.orc_gbuffer_block.argtypes = [vp, C.POINTER(OrcCamera)] + [C.c_uint32] * 6 + [C.c_float, vp]
+    L.orc_gbuffer_block.restype = None
     L.orc_set_rr_depth.argtypes = [C.c_uint32]
     L.orc_set_rr_depth.restype = None
     L.orc_set_anyhit_accounting.argtypes = [C.c_int]
@@ -275,6 +277,13 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def gbuffer(self, kind, rect, seed=12345):
+        d = self.desc
+        x0, y0, x1, y1 = rect
+        rgb = np.zeros((d.height, d.width, 3), dtype=np.float32)
+        self.L.orc_gbuffer_block(self.scene, C.byref(self.camera), x0, y0, x1, y1, kind, seed, d.exposure, vptr(rgb))
+        return rgb[y0:y1 + 1, x0:x1 + 1].copy()
 
     def env_tables(self):
         h, w, _ = self.desc.env.shape
@@ -419,6 +428,16 @@ def ref_bvh(desc, threaded=False):
     sbox = np.frombuffer(buf, dtype="<f4", count=6, offset=off).copy()
     (radius,) = struct.unpack_from("<f", buf, off + 24)
     return out, sbox, radius
+
+
+def ref_gbuffer(desc, kind, rect, seed=12345):
+    """GbufferVisualizer::TraceBlock of the compiled reference (kind 0 diffuse, 1 mesh normal, 2 normal), per-pixel states."""
+    x0, y0, x1, y1 = rect
+    with tempfile.TemporaryDirectory() as td:
+        sp, op = os.path.join(td, "s.prts"), os.path.join(td, "out.bin")
+        desc.write_prts(sp)
+        run_ref("ref_path", "gbuffer", sp, kind, x0, y0, x1, y1, seed, op)
+        return np.fromfile(op, dtype="<f4").reshape(y1 - y0 + 1, x1 - x0 + 1, 3).copy()
 
 
 def ref_envlight(desc, u):

@@ -601,3 +601,21 @@ def test_cpp_drop_in_driver_matches_python_host(tracer, tmp_path):
         img2 = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
     assert_bits_equal(np.ascontiguousarray(img2), ref, "C++ driver, per-tile calls")
     assert f"{tracer.last_stats['raysTraced']} rays" in out2.stdout
+
+
+def test_gbuffer_visualizer_matches_reference_and_oracle(tracer, c1):
+    """GbufferVisualizer (gbuffer_visualizer.cpp:17-51) on the traversal kernels' wave loop: Cornell + teapot
+    against the compiled reference's images (tests/golden/gbuffer.npz), the textured atrium against the oracle."""
+    z = np.load(os.path.join(G, "gbuffer.npz"))
+    scene, camera, exposure = prt_amd.setup_cornell_box(96, 96, teapot_mesh=T.teapot_product_mesh())
+    upload(tracer, scene, camera)
+    x0, y0, x1, y1 = (int(v) for v in z["rect"])
+    for k in (0, 1, 2):
+        assert_bits_equal(tracer.gbuffer(k, x0, y0, x1, y1), z[f"kind{k}"], f"gbuffer kind {k} vs compiled reference")
+    scene, camera, exposure = prt_amd.setup_atrium_standin(192, 108, tris=40000)
+    upload(tracer, scene, camera)
+    s = T.OracleScene(T.scene_desc_from_product(scene, camera, exposure))
+    for k in (0, 1):
+        assert_bits_equal(tracer.gbuffer(k, exposure=exposure), s.gbuffer(k, (0, 0, 191, 107)), f"atrium gbuffer kind {k}")
+    with pytest.raises(prt_amd.PrtError):
+        tracer.gbuffer(3)

@@ -212,3 +212,13 @@ def test_reference_own_test_program_passes():
     assert "assertion failed" not in p.stdout
     for name in ("test_vecmath()", "test_triangle_intersection()", "test_thread_pool()"):
         assert name in p.stdout
+
+
+def test_gbuffer_visualizer_matches_reference():
+    """GbufferVisualizer (gbuffer_visualizer.cpp:17-51) with the single jittered camera ray (camera.cpp:12-33) against the
+    compiled reference's images (fixture written by make_golden.dump_gbuffer)."""
+    z = np.load(os.path.join(G, "gbuffer.npz"))
+    s = T.OracleScene(T.cornell_scene(96, 96, with_teapot=True))
+    rect = tuple(int(v) for v in z["rect"])
+    for k in (0, 1, 2):
+        assert_bits_equal(s.gbuffer(k, rect), z[f"kind{k}"], f"gbuffer kind {k}")
