@@ -17,7 +17,9 @@
 #define PRT_STACK_LDS_PACKET 8 // the same for the packet traversal (8 B each: reference + entry distance)
 #endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
+#ifndef PRT_BLOCK
 #define PRT_BLOCK 256
+#endif
 #define PRT_MAT_STRIDE 5 // float4 per material record
 #ifndef PRT_TRI2
 #define PRT_TRI2 1 // a leaf step tests two triangles (one: 569 ms against 547 on C3)
