@@ -619,3 +619,52 @@ def test_gbuffer_visualizer_matches_reference_and_oracle(tracer, c1):
         assert_bits_equal(tracer.gbuffer(k, exposure=exposure), s.gbuffer(k, (0, 0, 191, 107)), f"atrium gbuffer kind {k}")
     with pytest.raises(prt_amd.PrtError):
         tracer.gbuffer(3)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_soups_match_oracle(tracer, seed):
+    """Seeded random scenes: triangle soups of mixed sizes (slivers, large overlapping triangles, duplicates), random diffuse /
+    specular / emissive materials over two meshes, random camera, directional light on or off.  Image, ray counts and event
+    counters equal the oracle's; NaN pixels (degenerate geometry can produce them in the reference too) must be NaN in both."""
+    rng = np.random.default_rng(1000 + seed)
+    scene = prt_amd.Scene()
+    for m in range(2):
+        n = int(rng.integers(40, 400))
+        centre = rng.uniform(-1, 1, size=(n, 1, 3))
+        size = np.exp(rng.uniform(np.log(0.01), np.log(0.8), size=(n, 1, 1)))
+        tri = (centre + size * rng.normal(size=(n, 3, 3))).astype(np.float32)
+        if seed % 2 == 0:
+            tri[:n // 20] = tri[n // 20:2 * (n // 20)]            # exact duplicates: ties at equal t
+            tri[-3:, 2] = tri[-3:, 1]                              # degenerate (zero-area) triangles
+        pos = tri.reshape(-1, 3)
+        idx = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+        kinds = rng.integers(0, 3, size=6)
+        mats = np.array([T.make_material(diffuse=tuple(rng.uniform(0.2, 0.9, 3)), reflection=int(k == 1),
+                                         emissive=tuple(rng.uniform(1, 6, 3)) if k == 2 else (0, 0, 0)) for k in kinds], dtype=T.MATERIAL_DTYPE)
+        pm = prt_amd.Mesh.from_arrays(idx, pos, rng.integers(0, 6, size=n).astype(np.uint32), mats.view(prt_amd.MATERIAL_DTYPE))
+        if m == 1:
+            pm.calculate_vertex_normals()
+        pm.calculate_bounds()
+        scene.add(pm)
+    if seed % 3 != 0:
+        scene.set_directional_light(_unit(rng.normal(size=3)), tuple(rng.uniform(1, 8, 3)))
+    eye = rng.uniform(-1, 1, 3) * 0.3 + np.array([0, 0, 3.0])
+    camera = prt_amd.Camera().create(tuple(eye), tuple(-eye + rng.normal(size=3) * 0.2), 56, 40)
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, 1.0)
+    rgb = tracer.render(16, max_depth=6, count_traffic=True)
+    st = tracer.last_stats
+    ref, ost = T.OracleScene(desc).render(16, max_depth=6)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(rgb), nan)
+    assert_bits_equal(rgb[~nan], ref[~nan], f"random soup {seed}")
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    timed = tracer.render(16, max_depth=6)
+    assert np.array_equal(np.isnan(timed), nan)
+    assert_bits_equal(timed[~nan], ref[~nan], f"random soup {seed}, timed build")
+
+
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return tuple((v / np.linalg.norm(v)).astype(np.float32))
