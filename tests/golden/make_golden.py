@@ -248,6 +248,20 @@ def dump_gbuffer():
     print("gbuffer means", {k: float(v.mean()) for k, v in out.items()})
 
 
+def dump_c1_checksums():
+    # BASELINE config 1 in full (Cornell + teapot, 512x512, 16 spp, the reference's depth literal 14) through the compiled
+    # reference: digests of the float image instead of the 3 MB image itself
+    import hashlib
+    desc = T.cornell_scene(512, 512, with_teapot=True)
+    rgb, st = T.ref_render(desc, 16, (0, 0, 511, 511), seed=12345, stats=True)
+    f64 = rgb.reshape(-1, 3).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, "c1_full_checksums.npz"), sum=f64.sum(0), sumsq=(f64 * f64).sum(0),
+                        sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8),
+                        rays=np.array([st["raysTraced"], st["occludedTraced"]], dtype=np.uint64),
+                        row_sums=rgb.astype(np.float64).sum(axis=(1, 2)))
+    print("C1 full image: sum", f64.sum(0), "rays", st)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", T.ORACLE_DIR])
     dump_cornell()
@@ -257,3 +271,4 @@ if __name__ == "__main__":
     dump_radiance()
     dump_env_light()
     dump_gbuffer()
+    dump_c1_checksums()

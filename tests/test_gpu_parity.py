@@ -668,3 +668,17 @@ def test_random_soups_match_oracle(tracer, seed):
 def _unit(v):
     v = np.asarray(v, dtype=np.float64)
     return tuple((v / np.linalg.norm(v)).astype(np.float32))
+
+
+def test_c1_full_image_digest_matches_compiled_reference(tracer, c1):
+    """BASELINE config 1 whole (512x512, 16 spp, depth literal 14): SHA-256 of the float image, ray count and row sums equal those
+    of the compiled reference's render (tests/golden/c1_full_checksums.npz; 18 080 026 rays)."""
+    import hashlib
+    scene, camera, desc = c1
+    upload(tracer, scene, camera)
+    z = np.load(os.path.join(G, "c1_full_checksums.npz"))
+    rgb = tracer.render(16, max_depth=14)
+    assert tracer.last_stats["raysTraced"] == int(z["rays"][0]) == 18080026 and tracer.last_stats["occludedTraced"] == 0
+    assert np.array_equal(rgb.astype(np.float64).sum(axis=(1, 2)), z["row_sums"])
+    digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(digest, z["sha256"])

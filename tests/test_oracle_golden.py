@@ -222,3 +222,16 @@ def test_gbuffer_visualizer_matches_reference():
     rect = tuple(int(v) for v in z["rect"])
     for k in (0, 1, 2):
         assert_bits_equal(s.gbuffer(k, rect), z[f"kind{k}"], f"gbuffer kind {k}")
+
+
+def test_c1_full_image_digest_matches_reference():
+    """The oracle's whole C1 image (512x512, 16 spp, depth 14) against the digest of the compiled reference's render."""
+    import hashlib
+    z = np.load(os.path.join(G, "c1_full_checksums.npz"))
+    s = T.OracleScene(T.cornell_scene(512, 512, with_teapot=True))
+    rgb, st = s.render(16, max_depth=14)
+    assert st["raysTraced"] == int(z["rays"][0]) and st["occludedTraced"] == int(z["rays"][1])
+    digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(digest, z["sha256"])
+    f64 = rgb.reshape(-1, 3).astype(np.float64)
+    assert np.array_equal(f64.sum(0), z["sum"]) and np.array_equal((f64 * f64).sum(0), z["sumsq"])
