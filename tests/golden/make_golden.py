@@ -28,6 +28,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # the repository root: prt_amd's host code builds the stand-in scenes
 import prt_testlib as T  # noqa: E402
 
 REF = "/root/reference"
@@ -262,6 +263,25 @@ def dump_c1_checksums():
     print("C1 full image: sum", f64.sum(0), "rays", st)
 
 
+def dump_scene_digests():
+    # Whole images of a C2-class scene (Cornell + displaced-sphere stand-in + directional light: packet and single occlusion
+    # rays) and a C3-class scene (textured atrium: alpha masks, bump map, vertex normals, depth 14) through the compiled
+    # reference (surface / texture members forwarded to the oracle by ref_glue.cpp).  Scenes come from the product's host code.
+    import hashlib
+    import prt_amd
+    out = {}
+    for name, (setup, kw, w, h) in {"c2": ("setup_bunny_standin", dict(tris=20000), 192, 192),
+                                    "c3": ("setup_atrium_standin", dict(tris=40000), 192, 108)}.items():
+        scene, camera, exposure = getattr(prt_amd, setup)(w, h, **kw)
+        desc = T.scene_desc_from_product(scene, camera, exposure)
+        rgb, st = T.ref_render(desc, 16, (0, 0, w - 1, h - 1), seed=12345, stats=True)
+        out[f"{name}_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
+        out[f"{name}_rays"] = np.array([st["raysTraced"], st["occludedTraced"]], dtype=np.uint64)
+        out[f"{name}_row_sums"] = rgb.astype(np.float64).sum(axis=(1, 2))
+        print(name, "mean", rgb.reshape(-1, 3).mean(0), st)
+    np.savez_compressed(os.path.join(HERE, "scene_digests.npz"), **out)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", T.ORACLE_DIR])
     dump_cornell()
@@ -272,3 +292,4 @@ if __name__ == "__main__":
     dump_env_light()
     dump_gbuffer()
     dump_c1_checksums()
+    dump_scene_digests()

@@ -682,3 +682,21 @@ def test_c1_full_image_digest_matches_compiled_reference(tracer, c1):
     assert np.array_equal(rgb.astype(np.float64).sum(axis=(1, 2)), z["row_sums"])
     digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
     assert np.array_equal(digest, z["sha256"])
+
+
+@pytest.mark.parametrize("name,setup,kw,w,h", [("c2", "setup_bunny_standin", dict(tris=20000), 192, 192),
+                                               ("c3", "setup_atrium_standin", dict(tris=40000), 192, 108)])
+def test_scene_digests_match_compiled_reference(tracer, name, setup, kw, w, h):
+    """Whole images of a C2-class scene (directional light: packet and single occlusion rays) and a C3-class scene (alpha masks,
+    bump map, vertex normals) at the reference's depth literal 14: digest, ray counts and row sums of the COMPILED REFERENCE's
+    render of the same scene (tests/golden/scene_digests.npz; its surface and texture members come from the oracle)."""
+    import hashlib
+    z = np.load(os.path.join(G, "scene_digests.npz"))
+    scene, camera, exposure = getattr(prt_amd, setup)(w, h, **kw)
+    upload(tracer, scene, camera)
+    rgb = tracer.render(16, max_depth=14, exposure=exposure)
+    st = tracer.last_stats
+    assert st["raysTraced"] == int(z[f"{name}_rays"][0]) and st["occludedTraced"] == int(z[f"{name}_rays"][1])
+    assert np.array_equal(rgb.astype(np.float64).sum(axis=(1, 2)), z[f"{name}_row_sums"])
+    digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(digest, z[f"{name}_sha256"])

@@ -235,3 +235,17 @@ def test_c1_full_image_digest_matches_reference():
     assert np.array_equal(digest, z["sha256"])
     f64 = rgb.reshape(-1, 3).astype(np.float64)
     assert np.array_equal(f64.sum(0), z["sum"]) and np.array_equal((f64 * f64).sum(0), z["sumsq"])
+
+
+@pytest.mark.parametrize("name,setup,kw,w,h", [("c2", "setup_bunny_standin", dict(tris=20000), 192, 192),
+                                               ("c3", "setup_atrium_standin", dict(tris=40000), 192, 108)])
+def test_scene_digests_match_reference(name, setup, kw, w, h):
+    """The oracle's whole images of the C2-class and C3-class test scenes against the compiled reference's digests."""
+    import hashlib
+    import prt_amd
+    z = np.load(os.path.join(G, "scene_digests.npz"))
+    scene, camera, exposure = getattr(prt_amd, setup)(w, h, **kw)
+    rgb, st = T.OracleScene(T.scene_desc_from_product(scene, camera, exposure)).render(16, max_depth=14)
+    assert st["raysTraced"] == int(z[f"{name}_rays"][0]) and st["occludedTraced"] == int(z[f"{name}_rays"][1])
+    digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(digest, z[f"{name}_sha256"])
