@@ -7,6 +7,8 @@
 //
 //   ./prt_main [cornell|bunny|atrium] [width height spp [tiles]]      (needs an MI355X; there is no CPU path)
 //   `tiles` drives the image the way the reference's main.cpp does: one TraceBlock per 16x16 tile from a thread pool
+//   ./prt_main twoscenes [width height spp]   two different scenes rendered back to back from the SAME stack slot, the way
+//   the reference's main() calls raytrace_scene() repeatedly (main.cpp:107-118, 192-200): render_a.pfm, render_b.pfm
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -77,9 +79,36 @@ static void setupAtriumStandIn(Scene& scene, Camera& camera, float& exposure, ui
     exposure = 1.0f;
 }
 
+// main.cpp:107-190 in short: a stack Scene, per-tile TraceBlock calls, save.  Called twice by `twoscenes`.
+static void raytraceScene(uint32_t width, uint32_t height, uint32_t samples, const char* imagePath, bool bunny)
+{
+    Scene scene;
+    Camera camera;
+    float exposure;
+    scene.init();
+    if (bunny) setupBunnyStandIn(scene, camera, exposure, width, height);
+    else setupCornellBox(scene, camera, exposure, width, height, nullptr);
+    Image image(width, height, true, exposure);
+    const uint32_t kTile = 16;
+    for (uint32_t y = 0; y < height; y += kTile)
+        for (uint32_t x = 0; x < width; x += kTile) {
+            PathTracer t;
+            t.TraceBlock(image, x, y, std::min(x + kTile, width - 1), std::min(y + kTile, height - 1), scene, camera, samples);
+        }
+    image.savePfm(imagePath);
+}
+
 int main(int argc, char** argv)
 {
     const char* which = argc > 1 ? argv[1] : "cornell";
+    if (!strcmp(which, "twoscenes")) {
+        uint32_t w = argc > 2 ? (uint32_t)atoi(argv[2]) : 128, h = argc > 3 ? (uint32_t)atoi(argv[3]) : 128;
+        uint32_t spp = argc > 4 ? (uint32_t)atoi(argv[4]) : 16;
+        raytraceScene(w, h, spp, "render_a.pfm", true);
+        raytraceScene(w, h, spp, "render_b.pfm", false); // same camera, same stack addresses, another scene
+        PathTracer::releaseDevice();
+        return 0;
+    }
     uint32_t width = argc > 2 ? (uint32_t)atoi(argv[2]) : 1024, height = argc > 3 ? (uint32_t)atoi(argv[3]) : 1024;
     const uint32_t kSamples = argc > 4 ? (uint32_t)atoi(argv[4]) : 64; // main.cpp:125
 

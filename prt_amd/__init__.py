@@ -104,8 +104,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 EXPORTS = [
     "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
     "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_render_gbuffer", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
-    "prt_hip_get_stats", "prt_hip_trace_rays", "prt_hip_test_leaf", "prt_hip_test_sincos", "prt_hip_test_powf",
-    "prt_hip_test_camera",
+    "prt_hip_get_stats",
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
     "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
     "prt_host_mesh_calculate_bounds", "prt_host_mesh_prim_count", "prt_host_scene_create", "prt_host_scene_destroy",
@@ -113,23 +112,42 @@ EXPORTS = [
     "prt_host_camera_create", "prt_host_bvh_build", "prt_host_free",
 ]
 
+# include/prt_hip_test.h: row-level entry points of the TEST build of the library (libprt_hip_test.so); the product does not export them
+TEST_EXPORTS = ["prt_hip_trace_rays", "prt_hip_test_leaf", "prt_hip_test_sincos", "prt_hip_test_powf", "prt_hip_test_camera"]
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libprt_hip_test.so")
+
 _lib = None
+_test_lib = None
 
 
 def build(force=False):
-    """Compile libprt_hip.so for gfx950 with hipcc (in tree)."""
+    """Compile libprt_hip.so (the product) and libprt_hip_test.so (the same sources plus the row-level test entry points)
+    for gfx950 with hipcc, in tree."""
+    _build.build_library(force=force, test_entry_points=True)
     return _build.build_library(force=force)
 
 
 def lib():
     """Load libprt_hip.so.  Fails loudly when it has not been built: the HIP library IS the product."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise PrtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    if _lib is None:
+        _lib = _load(LIB_PATH, False)
+    return _lib
+
+
+def test_lib():
+    """Load libprt_hip_test.so: the product's sources built with -DPRT_TEST_ENTRY_POINTS (row-level parity tests only)."""
+    global _test_lib
+    if _test_lib is None:
+        _test_lib = _load(TEST_LIB_PATH, True)
+    return _test_lib
+
+
+def _load(path, with_test_entry_points):
+    if not os.path.exists(path):
+        raise PrtError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950).  prt_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, f32p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.prt_hip_last_error.restype = C.c_char_p
     L.prt_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -145,11 +163,12 @@ def lib():
     L.prt_hip_framebuffer.restype = vp
     L.prt_hip_framebuffer.argtypes = [vp]
     L.prt_hip_get_stats.argtypes = [vp, C.POINTER(HipStats)]
-    L.prt_hip_trace_rays.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_float, vp]
-    L.prt_hip_test_leaf.argtypes = [vp, C.c_uint32, vp, vp]
-    L.prt_hip_test_sincos.argtypes = [vp, C.c_uint32, vp, vp, vp]
-    L.prt_hip_test_powf.argtypes = [vp, C.c_uint32, vp, vp]
-    L.prt_hip_test_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    if with_test_entry_points:
+        L.prt_hip_trace_rays.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_float, vp]
+        L.prt_hip_test_leaf.argtypes = [vp, C.c_uint32, vp, vp]
+        L.prt_hip_test_sincos.argtypes = [vp, C.c_uint32, vp, vp, vp]
+        L.prt_hip_test_powf.argtypes = [vp, C.c_uint32, vp, vp]
+        L.prt_hip_test_camera.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     for n in ("prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
               "prt_host_mesh_atrium", "prt_host_scene_create"):
         getattr(L, n).restype = vp
@@ -187,7 +206,6 @@ def lib():
     L.prt_host_bvh_build.argtypes = [C.c_uint32, vp, vp, C.c_int, C.POINTER(C.POINTER(BvhNode)), u32p, C.POINTER(u32p)]
     L.prt_host_free.argtypes = [vp]
     L.prt_host_free.restype = None
-    _lib = L
     return L
 
 
@@ -346,17 +364,23 @@ class Camera:
 class PathTracer:
     """prt::PathTracer (path_tracer.h:15-38) bound to one GPU through the C-ABI (include/prt_hip.h)."""
 
-    def __init__(self, device=0, max_depth=14, rr_depth=4, seed=12345):
-        L = lib()
+    def __init__(self, device=0, max_depth=14, rr_depth=4, seed=12345, test_entry_points=False):
+        """test_entry_points=True binds the TEST build of the library (row-level entry points for the parity tests)."""
+        L = self._L = test_lib() if test_entry_points else lib()
+        self._row_level = test_entry_points
         self._ctx = C.c_void_p()
-        _check(L.prt_hip_create(device, C.byref(self._ctx)), "prt_hip_create")
+        self._chk(L.prt_hip_create(device, C.byref(self._ctx)), "prt_hip_create")
         self.max_depth, self.rr_depth, self.seed = max_depth, rr_depth, seed
         self._scene = None
         self._camera = None
 
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PrtError(f"{what} failed ({rc}): {self._L.prt_hip_last_error().decode()}")
+
     def close(self):
         if getattr(self, "_ctx", None):
-            lib().prt_hip_destroy(self._ctx)
+            self._L.prt_hip_destroy(self._ctx)
             self._ctx = None
 
     __del__ = close
@@ -364,15 +388,15 @@ class PathTracer:
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_int()
-        _check(lib().prt_hip_device_info(self._ctx, name, 256, C.byref(cus)), "prt_hip_device_info")
+        self._chk(self._L.prt_hip_device_info(self._ctx, name, 256, C.byref(cus)), "prt_hip_device_info")
         return name.value.decode(), cus.value
 
     def upload_scene(self, scene):
-        _check(lib().prt_hip_upload_scene(self._ctx, scene.describe()), "prt_hip_upload_scene")
+        self._chk(self._L.prt_hip_upload_scene(self._ctx, scene.describe()), "prt_hip_upload_scene")
         self._scene = scene
 
     def set_camera(self, camera):
-        _check(lib().prt_hip_set_camera(self._ctx, C.byref(camera.desc)), "prt_hip_set_camera")
+        self._chk(self._L.prt_hip_set_camera(self._ctx, C.byref(camera.desc)), "prt_hip_set_camera")
         self._camera = camera
 
     def params(self, samples, exposure=1.0, rank=0, nranks=1, count_traffic=False, max_depth=None, tile=16):
@@ -390,14 +414,14 @@ class PathTracer:
     def render_async(self, x0, y0, x1, y1, samples, d_rgb=None, stream=None, **kw):
         """PathTracer::TraceBlock on the GPU; d_rgb = device pointer (int) or None for the context framebuffer."""
         p = self.params(samples, **kw)
-        _check(lib().prt_hip_render(self._ctx, x0, y0, x1, y1, C.byref(p), d_rgb, stream), "prt_hip_render")
+        self._chk(self._L.prt_hip_render(self._ctx, x0, y0, x1, y1, C.byref(p), d_rgb, stream), "prt_hip_render")
 
     def trace_block(self, x0, y0, x1, y1, samples, **kw):
         """Render the inclusive rectangle and return it as a (h, w, 3) float32 array."""
         self.render_async(x0, y0, x1, y1, samples, **kw)
         W, H = self._camera.width, self._camera.height
         img = np.zeros((H, W, 3), dtype=np.float32)
-        _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        self._chk(self._L.prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
         self.last_stats = self.stats()  # raises on stack overflow
         return img[y0:y1 + 1, x0:x1 + 1].copy()
 
@@ -406,9 +430,9 @@ class PathTracer:
         W, H = self._camera.width, self._camera.height
         x1 = W - 1 if x1 is None else x1
         y1 = H - 1 if y1 is None else y1
-        _check(lib().prt_hip_render_gbuffer(self._ctx, x0, y0, x1, y1, kind, self.seed, exposure, None, None), "prt_hip_render_gbuffer")
+        self._chk(self._L.prt_hip_render_gbuffer(self._ctx, x0, y0, x1, y1, kind, self.seed, exposure, None, None), "prt_hip_render_gbuffer")
         img = np.zeros((H, W, 3), dtype=np.float32)
-        _check(lib().prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        self._chk(self._L.prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
         return img[y0:y1 + 1, x0:x1 + 1].copy()
 
     def render(self, samples, **kw):
@@ -417,40 +441,49 @@ class PathTracer:
 
     def stats(self):
         st = HipStats()
-        _check(lib().prt_hip_get_stats(self._ctx, C.byref(st)), "prt_hip_get_stats")
+        self._chk(self._L.prt_hip_get_stats(self._ctx, C.byref(st)), "prt_hip_get_stats")
         return st.as_dict()
 
-    # ---- row-level entry points (parity tests)
+    # ---- row-level entry points (parity tests; include/prt_hip_test.h, test build of the library only)
+    def _need_row_level(self):
+        if not self._row_level:
+            raise PrtError("row-level entry points exist only in libprt_hip_test.so: PathTracer(test_entry_points=True)")
+
     def trace_rays(self, mode, org, dirs, max_t):
+        self._need_row_level()
         org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
         dirs = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         hits = np.zeros(len(org), dtype=HIT_DTYPE)
-        _check(lib().prt_hip_trace_rays(self._ctx, mode, len(org), org.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p),
+        self._chk(self._L.prt_hip_trace_rays(self._ctx, mode, len(org), org.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p),
                                         max_t, hits.ctypes.data_as(C.c_void_p)), "prt_hip_trace_rays")
         return hits
 
     def test_leaf(self, records):
+        self._need_row_level()
         rec = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 22)
         out = np.zeros((len(rec), 24), dtype=np.float32)
-        _check(lib().prt_hip_test_leaf(self._ctx, len(rec), rec.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "prt_hip_test_leaf")
+        self._chk(self._L.prt_hip_test_leaf(self._ctx, len(rec), rec.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "prt_hip_test_leaf")
         return out
 
     def test_sincos(self, theta):
+        self._need_row_level()
         th = np.ascontiguousarray(theta, dtype=np.float32)
         s, c = np.zeros_like(th), np.zeros_like(th)
-        _check(lib().prt_hip_test_sincos(self._ctx, len(th), th.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+        self._chk(self._L.prt_hip_test_sincos(self._ctx, len(th), th.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
                                          c.ctypes.data_as(C.c_void_p)), "prt_hip_test_sincos")
         return s, c
 
     def test_powf(self, x):
+        self._need_row_level()
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.zeros_like(x)
-        _check(lib().prt_hip_test_powf(self._ctx, len(x), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)), "prt_hip_test_powf")
+        self._chk(self._L.prt_hip_test_powf(self._ctx, len(x), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p)), "prt_hip_test_powf")
         return y
 
     def test_camera(self, x, y, state):
+        self._need_row_level()
         out = np.zeros(92, dtype=np.float32)
-        _check(lib().prt_hip_test_camera(self._ctx, x, y, state, out.ctypes.data_as(C.c_void_p)), "prt_hip_test_camera")
+        self._chk(self._L.prt_hip_test_camera(self._ctx, x, y, state, out.ctypes.data_as(C.c_void_p)), "prt_hip_test_camera")
         return out
 
 

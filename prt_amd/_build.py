@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libprt_hip.so")
+TEST_LIB = os.path.join(LIB_DIR, "libprt_hip_test.so")  # same sources + -DPRT_TEST_ENTRY_POINTS (include/prt_hip_test.h)
 
 SOURCES = [
     "prt_kernels.hip",
@@ -16,13 +17,13 @@ SOURCES = [
     "host/prt_host_capi.cpp",
 ]
 HEADERS = ["prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc", "../../include/prt_hip.h",
-           "../../include/prt_host.h"]
+           "../../include/prt_host.h", "../../include/prt_hip_test.h"]
 
 # -ffp-contract=off: the reference's object code has no FMA, and results must match it bit for bit.
 # No fast-math; HIP's default correctly-rounded f32 divide/sqrt is kept.
-# -fno-slp-vectorize: the trace kernels are VALU-issue-bound (PMC: 75 % busy at 24 of 64 lanes per instruction); the SLP
-# vectoriser's v_pk_* pairs cost more v_mov shuffling than they save (C3 frame 591 -> 551 ms).  The node step keeps its
-# hand-packed (lo, hi) slab pairs, whose operands come out of the loads already paired.
+# -fno-slp-vectorize: the SLP vectoriser's v_pk_* pairs cost more v_mov shuffling than they save (C3 frame 591 -> 551 ms,
+# measured); the node step keeps its hand-packed (lo, hi) slab pairs, whose operands come out of the loads already paired.
+# (What bounds the trace kernels is in DESIGN.md section 4, from the counter files under profiles/.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
@@ -34,22 +35,23 @@ def hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def build_library(force=False, verbose=False, test_entry_points=False):
+    lib = TEST_LIB if test_entry_points else LIB
+    if not force and not needs_build(lib):
+        return lib
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = f"{LIB}.tmp.{os.getpid()}"  # concurrent builders (several ranks) never share a partial file
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    tmp = f"{lib}.tmp.{os.getpid()}"  # concurrent builders (several ranks) never share a partial file
+    cmd = [hipcc()] + FLAGS + (["-DPRT_TEST_ENTRY_POINTS"] if test_entry_points else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, lib)
+    return lib

@@ -10,6 +10,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <limits>
@@ -210,7 +211,11 @@ public:
     float getRadius() const { return m_radius; }
     const BBox& getBBox() const { return m_bbox; }
     const std::vector<Bvh*>& getBvhs() const { return m_bvh; }
+    // Identity of the scene's CONTENTS for the device-side cache: drawn from one process-wide counter at construction, init()
+    // and every mutation, so (address, revision) never repeats -- a new Scene in a reused stack slot is a different scene.
     uint64_t getRevision() const { return m_revision; }
+    Scene();
+    ~Scene(); // drops any device-side copy keyed on this object
 
     // Flattens the scene into the C-ABI descriptor; `store` keeps the arrays the descriptor points to alive.
     struct DescStorage {
@@ -228,7 +233,8 @@ private:
     InfiniteAreaLight m_infiniteAreaLight;
     BBox m_bbox;
     float m_radius = 0.0f;
-    uint64_t m_revision = 0;
+    uint64_t m_revision;
+    static uint64_t nextRevision();
 };
 
 // ---- camera.h:14-53 ----
@@ -292,6 +298,18 @@ struct Stats {
         nodesTraversed += o.nodesTraversed; primsTraversed += o.primsTraversed; raysTraced += o.raysTraced;
         occludedTraced += o.occludedTraced; triTested += o.triTested;
     }
+};
+
+// stats.h:35-68: what main.cpp merges the per-tile tracers into (main.cpp:127-128, 148-150)
+struct TotalStats {
+    std::atomic<uint64_t> totalNodesTraversed, totalPrimsTraversed, totalRaysTraced, totalOccludedTraced, totalTriTested;
+    void clear() { totalNodesTraversed = totalPrimsTraversed = totalRaysTraced = totalOccludedTraced = totalTriTested = 0; }
+    void merge(const Stats& o)
+    {
+        totalNodesTraversed.fetch_add(o.nodesTraversed); totalPrimsTraversed.fetch_add(o.primsTraversed);
+        totalRaysTraced.fetch_add(o.raysTraced); totalOccludedTraced.fetch_add(o.occludedTraced); totalTriTested.fetch_add(o.triTested);
+    }
+    void print();
 };
 
 // ---- path_tracer.h:15-38.  TraceBlock renders the INCLUSIVE rectangle on the GPU (C-ABI prt_hip_render) and

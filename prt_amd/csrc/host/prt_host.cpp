@@ -114,6 +114,14 @@ void Mesh::calculateBounds() // mesh.cpp:302-309
 }
 
 // ---------------------------------------------------------------- scene (scene.cpp:9-27)
+uint64_t Scene::nextRevision()
+{
+    static std::atomic<uint64_t> counter{0};
+    return ++counter; // never 0, never repeated: a new Scene at a reused address cannot look like the old one
+}
+
+Scene::Scene() : m_revision(nextRevision()) {}
+
 void Scene::init()
 {
     m_directionalLight.init();
@@ -122,7 +130,7 @@ void Scene::init()
     m_bbox = BBox::init();
     m_radius = std::numeric_limits<float>::max();
     m_bvh.clear();
-    m_revision++;
+    m_revision = nextRevision();
 }
 
 void Scene::add(Bvh* bvh)
@@ -132,7 +140,7 @@ void Scene::add(Bvh* bvh)
     m_bbox.merge(bvh->m_mesh.getBBox());
     auto center = m_bbox.center();
     m_radius = length(m_bbox.upper - center);
-    m_revision++;
+    m_revision = nextRevision();
 }
 
 void Scene::setDirectionalLight(const Vector3f& dir, const Vector3f& intensity) // scene.h:30-35
@@ -140,7 +148,7 @@ void Scene::setDirectionalLight(const Vector3f& dir, const Vector3f& intensity) 
     m_directionalLight = {dir, intensity};
     m_availableLights |= (1u << (uint32_t)LightType::kDirectional);
     m_availableLights &= ~(1u << (uint32_t)LightType::kInfiniteArea);
-    m_revision++;
+    m_revision = nextRevision();
 }
 
 void Scene::setInfiniteAreaLight(const char* path) // scene.h:42-45
@@ -148,7 +156,7 @@ void Scene::setInfiniteAreaLight(const char* path) // scene.h:42-45
     m_infiniteAreaLight.create(path);
     if (!m_infiniteAreaLight.isValid()) return;
     m_availableLights |= (1u << (uint32_t)LightType::kInfiniteArea);
-    m_revision++;
+    m_revision = nextRevision();
 }
 
 void Scene::setInfiniteAreaLight(int32_t width, int32_t height, const float* rgba)
@@ -156,7 +164,7 @@ void Scene::setInfiniteAreaLight(int32_t width, int32_t height, const float* rgb
     m_infiniteAreaLight.create(width, height, rgba);
     if (!m_infiniteAreaLight.isValid()) return;
     m_availableLights |= (1u << (uint32_t)LightType::kInfiniteArea);
-    m_revision++;
+    m_revision = nextRevision();
 }
 
 // ---- light.cpp:13-84 ----
@@ -573,6 +581,29 @@ std::map<int, DeviceSlot> g_devices;
 }
 } // namespace
 
+// A Scene that goes away takes its device-side cache entries with it (the frame kept for per-tile callers included).
+Scene::~Scene()
+{
+    std::lock_guard<std::mutex> g(g_deviceMutex);
+    for (auto& kv : g_devices) {
+        if (kv.second.scene != this) continue;
+        kv.second.scene = nullptr;
+        kv.second.sceneRevision = 0;
+        kv.second.frameValid = false;
+        kv.second.haveFrameParams = false;
+    }
+}
+
+void TotalStats::print() // stats.h:59-66
+{
+    const float kToM = 1.0f / 1000000.0f;
+    logPrintf(LogLevel::kInfo, "Nodes traversed: %.3fM(%llu)\n", totalNodesTraversed.load() * kToM, (unsigned long long)totalNodesTraversed.load());
+    logPrintf(LogLevel::kInfo, "Prims traversed: %.3fM(%llu)\n", totalPrimsTraversed.load() * kToM, (unsigned long long)totalPrimsTraversed.load());
+    logPrintf(LogLevel::kInfo, "Rays traced: %.3fM(%llu)\n", totalRaysTraced.load() * kToM, (unsigned long long)totalRaysTraced.load());
+    logPrintf(LogLevel::kInfo, "Occluded traced: %.3fM(%llu)\n", totalOccludedTraced.load() * kToM, (unsigned long long)totalOccludedTraced.load());
+    logPrintf(LogLevel::kInfo, "Tri tested: %.3fM(%llu)\n", totalTriTested.load() * kToM, (unsigned long long)totalTriTested.load());
+}
+
 void PathTracer::releaseDevice()
 {
     std::lock_guard<std::mutex> g(g_deviceMutex);
@@ -612,6 +643,7 @@ void GbufferVisualizer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint3
     prt_camera_desc cd;
     bool sceneChanged, cameraChanged;
     DeviceSlot& slot = readySlot(m_device, scene, camera, cd, sceneChanged, cameraChanged);
+    if (image.getWidth() != cd.width || image.getHeigit() != cd.height) die("GbufferVisualizer::TraceBlock: the image and the camera differ in size");
     if (prt_hip_render_gbuffer(slot.ctx, x0, y0, x1, y1, (uint32_t)m_type, m_seed, image.getExposure(), nullptr, nullptr) != PRT_HIP_OK)
         die("prt_hip_render_gbuffer");
     if (prt_hip_download(slot.ctx, image.getPixels(), x0, y0, x1, y1) != PRT_HIP_OK) die("prt_hip_download");
@@ -636,6 +668,8 @@ void PathTracer::TraceBlock(Image& image, uint32_t x0, uint32_t y0, uint32_t x1,
     p.rank = 0;
     p.nranks = 1;
     const uint32_t W = cd.width, H = cd.height;
+    // the reference's writePixel strides by the IMAGE's width (image.cpp:44-50); rows are copied with the camera's here
+    if (image.getWidth() != W || image.getHeigit() != H) die("TraceBlock: the image and the camera differ in size");
     if (sceneChanged || cameraChanged || !slot.haveFrameParams || memcmp(&p, &slot.frameParams, sizeof(p)) != 0) {
         slot.frameParams = p;
         slot.haveFrameParams = true;

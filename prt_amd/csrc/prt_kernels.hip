@@ -840,6 +840,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
 }
 
 // ============================================================================ row-level test kernels
+// Only in the test build of the library (-DPRT_TEST_ENTRY_POINTS -> libprt_hip_test.so, include/prt_hip_test.h): the
+// product library exports neither these kernels nor their entry points.
+#ifdef PRT_TEST_ENTRY_POINTS
 struct RaysArgs {
     DevScene sc;
     uint32_t n;
@@ -970,6 +973,8 @@ __global__ void camera_kernel(DevCamera cam, uint32_t x, uint32_t y, uint32_t st
     }
 }
 
+#endif // PRT_TEST_ENTRY_POINTS
+
 // ============================================================================ host side of the C-ABI
 namespace {
 
@@ -1010,11 +1015,17 @@ inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 } // namespace
 
+#define PRT_TIMING_RING 32
 struct prt_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // one pair per render launch since the last get_stats
-    size_t eventsUsed = 0;
+    // Timing: a fixed ring of event pairs, one pair per render launch.  When the ring is full the oldest launches are folded
+    // into accMs (they have long finished), so a caller that renders in a loop without reading the stats holds no more than
+    // PRT_TIMING_RING pairs.
+    hipEvent_t evT0[PRT_TIMING_RING] = {}, evT1[PRT_TIMING_RING] = {};
+    uint32_t ringUsed = 0;
+    double accMs = 0.0, lastMs = 0.0;
+    uint64_t accLaunches = 0;
     int computeUnits = 0;
     std::string name;
     // scene
@@ -1104,22 +1115,10 @@ int prt_hip_device_count(void)
     return n;
 }
 
-int prt_hip_create(int device, prt_hip_ctx** out)
+static int create_resources(prt_hip_ctx* c)
 {
-    if (!out) return fail(PRT_HIP_EINVAL, "out is NULL");
-    // Four streams of this library run side by side; when the host process owns more streams (RCCL, a framework) the HIP
-    // runtime's default of four hardware queues makes them share.  Only read when the runtime initialises -- a no-op if the
-    // host already made a HIP call, and never overrides the host's own setting.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
-        return fail(PRT_HIP_ENODEVICE, "no HIP device: libprt_hip has no CPU path (the GPU kernels are the product)");
-    if (device < 0 || device >= n) return fail(PRT_HIP_EINVAL, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    prt_hip_ctx* c = new prt_hip_ctx();
-    c->device = device;
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
@@ -1134,6 +1133,29 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     HIP_TRY(hipMemset(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
+    return PRT_HIP_OK;
+}
+
+// The library runs four streams side by side.  A host process that owns more streams of its own (RCCL, a framework) should
+// raise the HIP runtime's default of four hardware queues BEFORE its first HIP call (GPU_MAX_HW_QUEUES); the
+// library does not touch the process environment.
+int prt_hip_create(int device, prt_hip_ctx** out)
+{
+    if (!out) return fail(PRT_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(PRT_HIP_ENODEVICE, "no HIP device: libprt_hip has no CPU path (the GPU kernels are the product)");
+    if (device < 0 || device >= n) return fail(PRT_HIP_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    prt_hip_ctx* c = new prt_hip_ctx();
+    c->device = device;
+    int rc = create_resources(c);
+    if (rc != PRT_HIP_OK) {
+        std::string why = g_err; // prt_hip_destroy makes HIP calls of its own
+        prt_hip_destroy(c);      // frees whatever was created before the failure
+        return fail(rc, why);
+    }
     *out = c;
     return PRT_HIP_OK;
 }
@@ -1149,16 +1171,16 @@ void prt_hip_destroy(prt_hip_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
     if (c->fb) (void)hipFree(c->fb);
     if (c->work) (void)hipFree(c->work);
     if (c->counters) (void)hipFree(c->counters);
     if (c->spill) (void)hipFree(c->spill);
     if (c->wfBuffer) (void)hipFree(c->wfBuffer);
-    for (auto& e : c->events) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
+    for (int k = 0; k < PRT_TIMING_RING; k++) {
+        if (c->evT0[k]) (void)hipEventDestroy(c->evT0[k]);
+        if (c->evT1[k]) (void)hipEventDestroy(c->evT1[k]);
     }
     for (int k = 0; k < (1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1; k++)
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
@@ -1229,13 +1251,20 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             if (mt.diffuseMap >= (int32_t)s->textureCount || mt.bumpMap >= (int32_t)s->textureCount)
                 return fail(PRT_HIP_EINVAL, "material texture index out of range");
             if (mt.alphaTest && mt.diffuseMap < 0) return fail(PRT_HIP_EINVAL, "alphaTest material without a diffuse map");
-            mats.push_back(make_float4(mt.diffuse[0], mt.diffuse[1], mt.diffuse[2], ubits(mt.reflectionType)));
-            mats.push_back(make_float4(mt.emissive[0], mt.emissive[1], mt.emissive[2], ubits(mt.alphaTest)));
-            mats.push_back(make_float4(ubits((uint32_t)mt.diffuseMap), ubits((uint32_t)mt.bumpMap), 0.0f, 0.0f));
-            for (int32_t tex : {mt.diffuseMap, mt.bumpMap}) {
-                const uint4 d = tex >= 0 ? texDesc[tex] : make_uint4(0, 0, 0, 0);
-                mats.push_back(make_float4(ubits(d.x), ubits(d.y), ubits(d.z), ubits(d.w)));
-            }
+            // ONE place writes a material record and its size is tied to the stride the kernels index with (sample_diffuse,
+            // sample_bump, shade_kernel: sc.mats + PRT_MAT_STRIDE * material).  A record count and an index stride that
+            // disagree read another material's fields as texture descriptors -- a wild texel address on the device.
+            const uint4 dd = mt.diffuseMap >= 0 ? texDesc[mt.diffuseMap] : make_uint4(0, 0, 0, 0);
+            const uint4 bd = mt.bumpMap >= 0 ? texDesc[mt.bumpMap] : make_uint4(0, 0, 0, 0);
+            const float4 record[] = {
+                make_float4(mt.diffuse[0], mt.diffuse[1], mt.diffuse[2], ubits(mt.reflectionType)),
+                make_float4(mt.emissive[0], mt.emissive[1], mt.emissive[2], ubits(mt.alphaTest)),
+                make_float4(ubits((uint32_t)mt.diffuseMap), ubits((uint32_t)mt.bumpMap), 0.0f, 0.0f),
+                make_float4(ubits(dd.x), ubits(dd.y), ubits(dd.z), ubits(dd.w)),
+                make_float4(ubits(bd.x), ubits(bd.y), ubits(bd.z), ubits(bd.w)),
+            };
+            static_assert(sizeof(record) / sizeof(record[0]) == PRT_MAT_STRIDE, "material record size and PRT_MAT_STRIDE must agree");
+            mats.insert(mats.end(), record, record + PRT_MAT_STRIDE);
         }
         // Wide records: one per internal node, in the reference's DFS order.  wideIndex[i] = record of node i.
         {
@@ -1381,6 +1410,17 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         sc.envFirstY = firstStep(s->envVerticalP, H);
         sc.hasEnv = 1;
     }
+    // every texture descriptor a kernel can reach lies inside the texel array (checked here, on the host, once per upload)
+    for (const uint4& d : texDesc)
+        if ((size_t)d.x + (size_t)d.y * d.z * d.w > texels.size()) return fail(PRT_HIP_EINVAL, "internal: texture descriptor outside the texel array");
+    for (size_t k = 0; k + PRT_MAT_STRIDE <= mats.size(); k += PRT_MAT_STRIDE)
+        for (int j = 3; j <= 4; j++) {
+            const float4& f = mats[k + j];
+            uint32_t off, w, h, comp;
+            memcpy(&off, &f.x, 4); memcpy(&w, &f.y, 4); memcpy(&h, &f.z, 4); memcpy(&comp, &f.w, 4);
+            if ((size_t)off + (size_t)w * h * comp > texels.size()) return fail(PRT_HIP_EINVAL, "internal: material map descriptor outside the texel array");
+        }
+    if (mats.size() % PRT_MAT_STRIDE != 0) return fail(PRT_HIP_EINVAL, "internal: material table is not a whole number of records");
     if ((rc = upload_vec(c, wnodes, &sc.wnodes))) return rc;
     if ((rc = upload_vec(c, tris, &sc.tris))) return rc;
     if ((rc = upload_vec(c, shade, &sc.shade))) return rc;
@@ -1471,6 +1511,20 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env
         for (int q = 0; q < Q_COUNT; q++) A[k].qE[q] = (uint32_t*)take(entries(slots) * sizeof(uint32_t));
     }
     return PRT_HIP_OK;
+}
+
+// Folds the recorded launches of the timing ring into the context's totals (waits for them: they were queued long ago).
+static void fold_timing(prt_hip_ctx* c)
+{
+    for (uint32_t i = 0; i < c->ringUsed; i++) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(c->evT1[i]) == hipSuccess && hipEventElapsedTime(&ms, c->evT0[i], c->evT1[i]) == hipSuccess) {
+            c->lastMs = ms;
+            c->accMs += ms;
+            c->accLaunches++;
+        }
+    }
+    c->ringUsed = 0;
 }
 
 int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, const prt_render_params* p, float* d_rgb,
@@ -1572,14 +1626,11 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     }
 
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
-    if (c->eventsUsed == c->events.size()) {
-        hipEvent_t a = nullptr, b = nullptr;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        c->events.emplace_back(a, b);
-    }
-    hipEvent_t ev0 = c->events[c->eventsUsed].first, ev1 = c->events[c->eventsUsed].second;
-    c->eventsUsed++;
+    if (c->ringUsed == PRT_TIMING_RING) fold_timing(c);
+    if (!c->evT0[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT0[c->ringUsed]));
+    if (!c->evT1[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT1[c->ringUsed]));
+    hipEvent_t ev0 = c->evT0[c->ringUsed], ev1 = c->evT1[c->ringUsed];
+    c->ringUsed++;
     HIP_TRY(hipEventRecord(ev0, s));
     const uint32_t iterations = (p->samples / 8) * (1 + p->maxDepth) + 1;
     for (uint64_t baseTile = 0; baseTile < totalTiles; baseTile += passTiles) {
@@ -1751,21 +1802,28 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     st->nTap = h[5];
     st->nPx = h[6];
     st->stackOverflow = h[7];
-    st->kernelMs = 0.0;
-    st->kernelMsSum = 0.0;
-    st->kernelLaunches = 0;
-    for (size_t i = 0; i < c->eventsUsed; i++) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second) == hipSuccess) {
-            st->kernelMs = ms;
-            st->kernelMsSum += ms;
-            st->kernelLaunches++;
-        }
-    }
-    c->eventsUsed = 0;
+    fold_timing(c);
+    st->kernelMs = c->accLaunches ? c->lastMs : 0.0;
+    st->kernelMsSum = c->accMs;
+    st->kernelLaunches = c->accLaunches;
+    c->accMs = c->lastMs = 0.0;
+    c->accLaunches = 0;
     if (h[7]) return fail(PRT_HIP_ESTACK, "BVH traversal needed more than 64 stack entries (the reference asserts here, bvh.cpp:552)");
     return PRT_HIP_OK;
 }
+
+#ifdef PRT_TEST_ENTRY_POINTS
+} // extern "C"
+namespace {
+// device scratch of one test call: freed on every return path
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+} // namespace
+extern "C" {
 
 int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, const float* dir, float maxT, prt_hit* hits)
 {
@@ -1776,16 +1834,15 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     uint32_t blocks = (n + PRT_BLOCK - 1) / PRT_BLOCK;
     int rc = ensure_launch_resources(c, blocks);
     if (rc) return rc;
-    float *dorg = nullptr, *ddir = nullptr;
-    prt_hit* dh = nullptr;
-    HIP_TRY(hipMalloc(&dorg, (size_t)n * 12));
-    HIP_TRY(hipMalloc(&ddir, (size_t)n * 12));
-    HIP_TRY(hipMalloc(&dh, (size_t)n * sizeof(prt_hit)));
-    HIP_TRY(hipMemcpy(dorg, org, (size_t)n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ddir, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+    DevBuf dorg, ddir, dh;
+    HIP_TRY(dorg.alloc((size_t)n * 12));
+    HIP_TRY(ddir.alloc((size_t)n * 12));
+    HIP_TRY(dh.alloc((size_t)n * sizeof(prt_hit)));
+    HIP_TRY(hipMemcpy(dorg.p, org, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ddir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->work, 0, 1024, c->stream));
-    RaysArgs A{c->sc, n, dorg, ddir, maxT, dh, c->work, c->spill, c->spillThreads, c->counters};
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), c->stream));
+    RaysArgs A{c->sc, n, dorg.as<float>(), ddir.as<float>(), maxT, dh.as<prt_hit>(), c->work, c->spill, c->spillThreads, c->counters};
     blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
     if (mode == 0) hipLaunchKernelGGL(rays_kernel<PRT_MODE_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     else if (mode == 1) hipLaunchKernelGGL(rays_kernel<PRT_MODE_PACKET>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
@@ -1794,10 +1851,7 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("rays_kernel launch: ") + hipGetErrorString(le));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(hits, dh, (size_t)n * sizeof(prt_hit), hipMemcpyDeviceToHost));
-    (void)hipFree(dorg);
-    (void)hipFree(ddir);
-    (void)hipFree(dh);
+    HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(prt_hit), hipMemcpyDeviceToHost));
     c->timed = false;
     return PRT_HIP_OK;
 }
@@ -1806,15 +1860,13 @@ int prt_hip_test_leaf(prt_hip_ctx* c, uint32_t n, const float* records, float* o
 {
     if (!c || !records || !out || n == 0) return fail(PRT_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    float *din = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc(&din, (size_t)n * 22 * 4));
-    HIP_TRY(hipMalloc(&dout, (size_t)n * 24 * 4));
-    HIP_TRY(hipMemcpy(din, records, (size_t)n * 22 * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(leaf_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din, dout);
+    DevBuf din, dout;
+    HIP_TRY(din.alloc((size_t)n * 22 * 4));
+    HIP_TRY(dout.alloc((size_t)n * 24 * 4));
+    HIP_TRY(hipMemcpy(din.p, records, (size_t)n * 22 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(leaf_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, din.as<float>(), dout.as<float>());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 24 * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(din);
-    (void)hipFree(dout);
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 24 * 4, hipMemcpyDeviceToHost));
     return PRT_HIP_OK;
 }
 
@@ -1822,18 +1874,15 @@ int prt_hip_test_sincos(prt_hip_ctx* c, uint32_t n, const float* theta, float* s
 {
     if (!c || !theta || !s || !cs || n == 0) return fail(PRT_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    float *dt = nullptr, *ds = nullptr, *dc = nullptr;
-    HIP_TRY(hipMalloc(&dt, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&ds, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&dc, (size_t)n * 4));
-    HIP_TRY(hipMemcpy(dt, theta, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dt, ds, dc);
+    DevBuf dt, ds, dc;
+    HIP_TRY(dt.alloc((size_t)n * 4));
+    HIP_TRY(ds.alloc((size_t)n * 4));
+    HIP_TRY(dc.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(dt.p, theta, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dt.as<float>(), ds.as<float>(), dc.as<float>());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(s, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cs, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dt);
-    (void)hipFree(ds);
-    (void)hipFree(dc);
+    HIP_TRY(hipMemcpy(s, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cs, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PRT_HIP_OK;
 }
 
@@ -1841,15 +1890,13 @@ int prt_hip_test_powf(prt_hip_ctx* c, uint32_t n, const float* x, float* y)
 {
     if (!c || !x || !y || n == 0) return fail(PRT_HIP_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    float *dx = nullptr, *dy = nullptr;
-    HIP_TRY(hipMalloc(&dx, (size_t)n * 4));
-    HIP_TRY(hipMalloc(&dy, (size_t)n * 4));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(powf_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, dy);
+    DevBuf dx, dy;
+    HIP_TRY(dx.alloc((size_t)n * 4));
+    HIP_TRY(dy.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(powf_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx.as<float>(), dy.as<float>());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dx);
-    (void)hipFree(dy);
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PRT_HIP_OK;
 }
 
@@ -1858,13 +1905,13 @@ int prt_hip_test_camera(prt_hip_ctx* c, uint32_t x, uint32_t y, uint32_t state, 
     if (!c || !out92) return fail(PRT_HIP_EINVAL, "bad argument");
     if (!c->haveCamera) return fail(PRT_HIP_ESTATE, "set a camera first");
     HIP_TRY(hipSetDevice(c->device));
-    float* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 92 * 4));
-    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(64), 0, c->stream, c->cam, x, y, state, d);
+    DevBuf d;
+    HIP_TRY(d.alloc(92 * 4));
+    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(64), 0, c->stream, c->cam, x, y, state, d.as<float>());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out92, d, 92 * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    HIP_TRY(hipMemcpy(out92, d.p, 92 * 4, hipMemcpyDeviceToHost));
     return PRT_HIP_OK;
 }
+#endif // PRT_TEST_ENTRY_POINTS
 
 } // extern "C"

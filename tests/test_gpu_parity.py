@@ -45,6 +45,16 @@ def tracer():
 
 
 @pytest.fixture(scope="module")
+def rows():
+    """A context of the TEST build of the library (libprt_hip_test.so: the product's sources + the row-level entry points
+    of include/prt_hip_test.h).  Whole-image tests run on `tracer`, the product library."""
+    prt_amd.build()
+    t = prt_amd.PathTracer(test_entry_points=True)
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="module")
 def c1(tracer):
     """Config C1 scene (Cornell + teapot, 512x512) uploaded, with the oracle's twin."""
     scene, camera, exposure = prt_amd.setup_cornell_box(512, 512, teapot_mesh=T.teapot_product_mesh())
@@ -58,9 +68,9 @@ def upload(tracer, scene, camera):
 
 
 # ----------------------------------------------------------------------------- leaf rows (a3, a4, a10, box tests)
-def test_leaf_math_matches_reference_vectors(tracer):
+def test_leaf_math_matches_reference_vectors(rows):
     z = np.load(os.path.join(G, "leaf_vectors.npz"))
-    out = tracer.test_leaf(z["inputs"])
+    out = rows.test_leaf(z["inputs"])
     ref = z["outputs"]
     cols = [c for c in range(23) if c not in (8, 9, 10, 11, 15)]  # scalar triangle + SoA box->t are not on the path
     a, b = out[:, cols], ref[:, cols]
@@ -69,56 +79,56 @@ def test_leaf_math_matches_reference_vectors(tracer):
     assert out[0, 0] == 1.0  # the reference's own known answer, tests/tests.cpp:109-127
 
 
-def test_sincos_matches_libm_on_all_path_arguments(tracer, oracle_lib):
+def test_sincos_matches_libm_on_all_path_arguments(rows, oracle_lib):
     k = np.arange(1 << 23, dtype=np.uint32)
     r1 = (k | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
     theta = (np.float32(2.0) * np.float32(3.14159265358979323846) * r1).astype(np.float32)
-    s, c = tracer.test_sincos(theta)
+    s, c = rows.test_sincos(theta)
     rs, rc = np.zeros_like(theta), np.zeros_like(theta)
     oracle_lib.orc_libm_sincos(len(theta), T.vptr(theta), T.vptr(rs), T.vptr(rc))
     assert_bits_equal(s, rs, "sinf")
     assert_bits_equal(c, rc, "cosf")
 
 
-def test_powf_matches_libm(tracer, oracle_lib):
+def test_powf_matches_libm(rows, oracle_lib):
     rng = np.random.default_rng(5)
     x = np.concatenate([rng.uniform(0, 1, 1 << 20), np.arange(256) / 255.0, [0.0, 1.0, 1e-30, 2.0 ** -24]]).astype(np.float32)
-    y = tracer.test_powf(x)
+    y = rows.test_powf(x)
     ref = np.zeros_like(x)
     oracle_lib.orc_libm_powf22(len(x), T.vptr(x), T.vptr(ref))
     assert_bits_equal(y, ref, "powf(x, 2.2)")
 
 
-def test_camera_packets_match_reference(tracer, c1):
+def test_camera_packets_match_reference(rows, c1):
     scene, camera, _ = c1
-    upload(tracer, scene, camera)
+    upload(rows, scene, camera)
     z = np.load(os.path.join(G, "camera_packets.npz"))
     for (x, y, state), ref in zip(z["xys"], z["out"]):
-        out = tracer.test_camera(int(x), int(y), int(state))
+        out = rows.test_camera(int(x), int(y), int(state))
         assert_bits_equal(out[:92], ref[:92], f"camera packet at ({x},{y})")
 
 
 # ----------------------------------------------------------------------------- traversal rows (a5-a9, a11)
-def test_traversals_match_reference_rays(tracer, c1):
+def test_traversals_match_reference_rays(rows, c1):
     scene, camera, _ = c1
-    upload(tracer, scene, camera)
+    upload(rows, scene, camera)
     z = np.load(os.path.join(G, "rays_cornell_teapot.npz"))
     far = float(z["max_t"])
     for mode, key in ((0, "single"), (1, "packet")):
-        got = tracer.trace_rays(mode, z["org"], z["dir"], far)
+        got = rows.trace_rays(mode, z["org"], z["dir"], far)
         ref = z[key].view(T.HIT_DTYPE).reshape(-1)
         assert_bits_equal(got["t"], ref["t"], key + ".t")
         hit = ref["t"] != -1
         for f in ("i", "j", "k"):
             assert_bits_equal(got[f][hit], ref[f][hit], key + "." + f)
         assert (got["primId"][hit] == ref["primId"][hit]).all() and (got["meshId"][hit] == ref["meshId"][hit]).all()
-    assert (tracer.trace_rays(2, z["org"], z["dir"], far)["t"] == z["occluded_single"]).all()
-    assert (tracer.trace_rays(3, z["org"], z["dir"], far)["t"] == z["occluded_packet"]).all()
+    assert (rows.trace_rays(2, z["org"], z["dir"], far)["t"] == z["occluded_single"]).all()
+    assert (rows.trace_rays(3, z["org"], z["dir"], far)["t"] == z["occluded_packet"]).all()
 
 
-def test_traversals_match_oracle_on_fresh_rays(tracer, c1):
+def test_traversals_match_oracle_on_fresh_rays(rows, c1):
     scene, camera, desc = c1
-    upload(tracer, scene, camera)
+    upload(rows, scene, camera)
     s = T.OracleScene(desc)
     rng = np.random.default_rng(99)
     n = 2048
@@ -131,10 +141,10 @@ def test_traversals_match_oracle_on_fresh_rays(tracer, c1):
     os_, oc1 = s.intersect_single(org, d, far)
     op, oc8 = s.intersect_packet(org, d, far)
     for mode, ref in ((0, os_), (1, op)):
-        got = tracer.trace_rays(mode, org, d, far)
+        got = rows.trace_rays(mode, org, d, far)
         assert got.tobytes() == ref.tobytes(), f"mode {mode}"
-    assert (tracer.trace_rays(2, org, d, far)["t"] == oc1).all()
-    assert (tracer.trace_rays(3, org, d, far)["t"] == oc8).all()
+    assert (rows.trace_rays(2, org, d, far)["t"] == oc1).all()
+    assert (rows.trace_rays(3, org, d, far)["t"] == oc8).all()
 
 
 # ----------------------------------------------------------------------------- the whole path (a1, a2, a12, a13)
@@ -244,13 +254,16 @@ def test_ragged_rectangles_and_rank_interleave(tracer, c1):
     assert_bits_equal(acc, full, "rank-interleaved union")
 
 
-def test_error_behaviour(tracer, c1):
+def test_error_behaviour(tracer, rows, c1):
     scene, camera, _ = c1
     upload(tracer, scene, camera)
     with pytest.raises(prt_amd.PrtError, match="outside the image"):
         tracer.trace_block(0, 0, 512, 10, 8)
+    upload(rows, scene, camera)
     with pytest.raises(prt_amd.PrtError):
-        tracer.trace_rays(0, np.zeros((7, 3)), np.zeros((7, 3)), 1.0)
+        rows.trace_rays(0, np.zeros((7, 3)), np.zeros((7, 3)), 1.0)
+    with pytest.raises(prt_amd.PrtError, match="libprt_hip_test"):  # the product library has no row-level entry points
+        tracer.trace_rays(0, np.zeros((8, 3)), np.zeros((8, 3)), 1.0)
 
 
 # ----------------------------------------------------------------------------- BASELINE full size: properties
@@ -302,13 +315,14 @@ def _tree_depth(nodes):
     return depth
 
 
-def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer):
+def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer, rows):
     """A tree deeper than the 16 stack entries kept in LDS (the rest of the 64 spill to HBM)."""
     idx, pos, pm, mats = _geometric_soup(56)
     scene = prt_amd.Scene()
     scene.add(prt_amd.Mesh.from_arrays(idx, pos, pm, mats.view(prt_amd.MATERIAL_DTYPE)))
     camera = prt_amd.Camera().create((-4, 0, 0), (1, 0, 0), 32, 32)
     upload(tracer, scene, camera)
+    upload(rows, scene, camera)
     desc = T.scene_desc_from_product(scene, camera)
     assert 17 < _tree_depth(desc.product_arrays["meshes"][0]["nodes"]) < 60  # deeper than the 16 LDS entries
     s = T.OracleScene(desc)
@@ -326,16 +340,16 @@ def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer):
     far = float(np.float32(2.0) * np.float32(s.radius()))
     os_, oc1 = s.intersect_single(org, d, far)
     op, oc8 = s.intersect_packet(org, d, far)
-    assert tracer.trace_rays(0, org, d, far).tobytes() == os_.tobytes()
-    assert tracer.trace_rays(1, org, d, far).tobytes() == op.tobytes()
-    assert (tracer.trace_rays(2, org, d, far)["t"] == oc1).all()
-    assert (tracer.trace_rays(3, org, d, far)["t"] == oc8).all()
+    assert rows.trace_rays(0, org, d, far).tobytes() == os_.tobytes()
+    assert rows.trace_rays(1, org, d, far).tobytes() == op.tobytes()
+    assert (rows.trace_rays(2, org, d, far)["t"] == oc1).all()
+    assert (rows.trace_rays(3, org, d, far)["t"] == oc8).all()
     rgb = tracer.render(8)
     ref, _ = s.render(8)
     assert_bits_equal(rgb, ref, "deep-tree radiance")
 
 
-def test_stack_overflow_is_reported_like_the_reference_assert(tracer):
+def test_stack_overflow_is_reported_like_the_reference_assert(rows):
     """The reference asserts when its 64-entry stack overflows (bvh.cpp:552, 627); the C-ABI returns PRT_HIP_ESTACK.
     The binned-SAH builder does not produce such trees from sane input, so a hand-made chain BVH (every level pushes its
     second child and descends into the first) is uploaded through the C-ABI descriptor."""
@@ -368,16 +382,16 @@ def test_stack_overflow_is_reported_like_the_reference_assert(tracer):
     md.materials = mats.ctypes.data_as(C.POINTER(prt_amd.Material))
     sd = prt_amd.SceneDesc()
     sd.meshCount, sd.meshes, sd.radius = 1, C.pointer(md), 1e4
-    prt_amd._check(prt_amd.lib().prt_hip_upload_scene(tracer._ctx, C.byref(sd)), "upload")
+    rows._chk(rows._L.prt_hip_upload_scene(rows._ctx, C.byref(sd)), "upload")
     org = np.tile(np.array([[0.0, 0.2, 0.2]], dtype=np.float32), (8, 1))
     d = np.tile(np.array([[1.0, 0, 0]], dtype=np.float32), (8, 1))
     for mode in (0, 1, 2, 3):
-        tracer.trace_rays(mode, org, d, 100.0)
+        rows.trace_rays(mode, org, d, 100.0)
         if mode == 0:
-            tracer.stats()  # near-first single traversal pops as it goes on this chain: no overflow
+            rows.stats()  # near-first single traversal pops as it goes on this chain: no overflow
             continue
         with pytest.raises(prt_amd.PrtError, match="64 stack entries"):
-            tracer.stats()
+            rows.stats()
 
 
 def test_large_scene_4k_two_passes_matches_oracle_tiles(tracer):
@@ -510,8 +524,7 @@ def test_full_size_c3_properties(tracer):
     rays = 0
     for r in range(3):
         tracer.render_async(0, 0, W - 1, H - 1, spp, max_depth=depth, exposure=exposure, rank=r, nranks=3)
-        part = np.zeros_like(a)
-        prt_amd._check(prt_amd.lib().prt_hip_download(tracer._ctx, part.ctypes.data_as(prt_amd.C.c_void_p), 0, 0, W - 1, H - 1), "download")
+        part = _download(tracer, a)
         mask = prt_amd.owned_pixel_mask(W, H, r, 3)
         union[mask] = part[mask]
         rays += tracer.stats()["raysTraced"]
@@ -524,6 +537,77 @@ def test_full_size_c3_properties(tracer):
     for (x0, y0) in ((952, 532), (64, 1000), (1800, 40), (1904, 1064)):
         ref, _ = s.trace_block(x0, y0, x0 + 15, y0 + 15, spp, max_depth=depth)
         assert_bits_equal(a[y0:y0 + 16, x0:x0 + 16], ref, f"tile at {(x0, y0)}")
+
+
+def _download(tracer, like):
+    out = np.zeros_like(like)
+    H, W, _ = like.shape
+    tracer._chk(tracer._L.prt_hip_download(tracer._ctx, out.ctypes.data_as(prt_amd.C.c_void_p), 0, 0, W - 1, H - 1), "download")
+    return out
+
+
+def test_full_size_c4_workload(tracer):
+    """BASELINE config 4 AT ITS WORKLOAD: San-Miguel-class stand-in (2.5 M triangles, alpha-masked cards, bump map, directional
+    light; light and camera set-up as main.cpp:75-91), 1920x1080, 256 spp, depth cap 14 (the reference's literal), whole
+    frame on one GPU.  Size-independent properties: repeatable; the union of the 8 ranks' shares -- what the 8 GPUs of the
+    config render -- is the single-GPU image with the same ray total; tiles across the frame equal the oracle at 256 spp."""
+    W, H, spp, depth = 1920, 1080, 256, 14
+    scene, camera, exposure = prt_amd.setup_atrium_standin(W, H, tris=2500000, seed=4)
+    upload(tracer, scene, camera)
+    a = tracer.render(spp, max_depth=depth, exposure=exposure)
+    sa = tracer.last_stats
+    assert sa["nPx"] == W * H and sa["stackOverflow"] == 0 and sa["raysTraced"] >= spp * W * H and sa["occludedTraced"] > 0
+    assert np.isfinite(a).all() and (a >= 0).all()
+    print(f"C4 frame: {sa['raysTraced'] / 1e9:.2f} G rays in {sa['kernelMs']:.0f} ms = {sa['raysTraced'] / sa['kernelMs'] / 1e3:.0f} Mray/s")
+    b = tracer.render(spp, max_depth=depth, exposure=exposure)
+    assert a.tobytes() == b.tobytes() and tracer.last_stats["raysTraced"] == sa["raysTraced"]
+    union = np.zeros_like(a)
+    rays = occl = px = 0
+    for r in range(8):
+        tracer.render_async(0, 0, W - 1, H - 1, spp, max_depth=depth, exposure=exposure, rank=r, nranks=8)
+        part = _download(tracer, a)
+        mask = prt_amd.owned_pixel_mask(W, H, r, 8)
+        union[mask] = part[mask]
+        st = tracer.stats()
+        rays, occl, px = rays + st["raysTraced"], occl + st["occludedTraced"], px + st["nPx"]
+        assert st["nPx"] == int(mask.sum())
+    assert union.tobytes() == a.tobytes()
+    assert (rays, occl, px) == (sa["raysTraced"], sa["occludedTraced"], W * H)
+    s = T.OracleScene(T.scene_desc_from_product(scene, camera, exposure))
+    for (x0, y0) in ((944, 528), (48, 1008), (1808, 32), (1904, 1064)):
+        ref, _ = s.render_rect((x0, y0, x0 + 15, y0 + 15), spp, max_depth=depth, stats=False)
+        assert_bits_equal(a[y0:y0 + 16, x0:x0 + 16], ref, f"C4 tile at {(x0, y0)}")
+
+
+def test_full_size_c5_workload_one_rank_of_eight(tracer):
+    """BASELINE config 5 AT ITS WORKLOAD, as ONE of its 8 GPUs runs it: Zero-Day-class stand-in (5 M triangles, 10 % of them
+    emissive, no directional light, exposure 64; main.cpp:93-105), 3840x2160, 1024 spp, depth cap 12, rank 3 of 8 (every 8th
+    16x16 tile).  Checked: exactly the rank's pixels are written, the closed form of the primary ray count, and tiles of
+    the rank equal the oracle at 1024 spp.  (A whole 4K frame is two wavefront passes: test_large_scene_4k_two_passes...;
+    one rank's share of it is one.)"""
+    W, H, spp, depth, rank, nranks = 3840, 2160, 1024, 12, 3, 8
+    scene, camera, _ = prt_amd.setup_atrium_standin(W, H, tris=5000000, seed=5, emissive_fraction=0.1, light=False)
+    exposure = 64.0
+    upload(tracer, scene, camera)
+    tracer.render_async(0, 0, W - 1, H - 1, spp, max_depth=depth, exposure=exposure, rank=rank, nranks=nranks)
+    img = _download(tracer, np.zeros((H, W, 3), dtype=np.float32))
+    st = tracer.stats()
+    mask = prt_amd.owned_pixel_mask(W, H, rank, nranks)
+    assert st["nPx"] == int(mask.sum()) and st["stackOverflow"] == 0 and st["occludedTraced"] == 0
+    assert st["raysTraced"] >= spp * int(mask.sum())
+    assert np.isfinite(img[mask]).all() and (img[mask] >= 0).all()
+    print(f"C5 share: {st['raysTraced'] / 1e9:.2f} G rays in {st['kernelMs']:.0f} ms = {st['raysTraced'] / st['kernelMs'] / 1e3:.0f} Mray/s")
+    tiles_x = W // 16
+    s = T.OracleScene(T.scene_desc_from_product(scene, camera, exposure))
+    picked = []
+    for (tx, ty) in ((119, 67), (3, 2), (236, 133), (40, 100)):  # the nearest tile this rank owns
+        t = ty * tiles_x + tx
+        t += (rank - t % nranks) % nranks
+        picked.append((t % tiles_x * 16, t // tiles_x * 16))
+    for (x0, y0) in picked:
+        assert mask[y0, x0]
+        ref, _ = s.render_rect((x0, y0, x0 + 15, y0 + 15), spp, max_depth=depth, stats=False)
+        assert_bits_equal(img[y0:y0 + 16, x0:x0 + 16], ref, f"C5 tile at {(x0, y0)}")
 
 
 @pytest.mark.parametrize("spp,max_depth,seed,tile", [(24, 14, 12345, 16), (8, 1, 777, 16), (4, 14, 12345, 16), (16, 2, 1, 8), (16, 6, 99, 32),
@@ -601,6 +685,36 @@ def test_cpp_drop_in_driver_matches_python_host(tracer, tmp_path):
         img2 = np.frombuffer(f.read(), dtype="<f4").reshape(H, W, 3)[::-1]
     assert_bits_equal(np.ascontiguousarray(img2), ref, "C++ driver, per-tile calls")
     assert f"{tracer.last_stats['raysTraced']} rays" in out2.stdout
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(v) for v in f.readline().split())
+        assert float(f.readline()) < 0  # little-endian
+        return np.ascontiguousarray(np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)[::-1])  # rows run bottom to top
+
+
+def test_cpp_driver_two_scenes_from_one_stack_slot(tracer, tmp_path):
+    """The reference's main() calls raytrace_scene() for one scene after another, each with a stack `Scene scene;`
+    (main.cpp:107-118, 192-200): the second Scene lives at the first one's address and here has the SAME camera.  The
+    host's device-side cache is keyed on (address, process-wide revision) and dropped by ~Scene, so the second call
+    must upload and render the second scene -- not serve the first one's BVH or its kept frame."""
+    import subprocess
+    ex = os.path.join(T.ROOT, "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    W, H, spp = 96, 80, 8
+    out = subprocess.run([os.path.join(ex, "prt_main"), "twoscenes", str(W), str(H), str(spp)], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    a, b = read_pfm(tmp_path / "render_a.pfm"), read_pfm(tmp_path / "render_b.pfm")
+    scene, camera, exposure = prt_amd.setup_bunny_standin(W, H, tris=69451)
+    upload(tracer, scene, camera)
+    assert_bits_equal(a, tracer.render(spp, exposure=exposure), "first scene (bunny stand-in)")
+    scene, camera, exposure = prt_amd.setup_cornell_box(W, H)
+    upload(tracer, scene, camera)
+    assert_bits_equal(b, tracer.render(spp, exposure=exposure), "second scene (Cornell box) from the same stack slot")
+    assert a.tobytes() != b.tobytes()
 
 
 def test_gbuffer_visualizer_matches_reference_and_oracle(tracer, c1):
