@@ -10,7 +10,8 @@ the configuration BASELINE.json's metric is quoted on -- "Mray/s at 1080p/64spp"
 Sponza-class scene at 1920x1080, 64 spp, depth cap 8 on one MI355X (the reference's sponza.obj is not
 shipped; a seeded procedural stand-in of the same triangle count, alpha-masked textures and a bump map is
 used).  With N > 1 the image's 16x16 tiles are dealt round-robin to the ranks (every rank holds
-the whole scene, no data-path collective) and the only exchange is the final image gather over RCCL.
+the whole scene, no data-path collective) and the only exchange is the final image gather over RCCL, inside the library
+(prt_hip_gather_rccl: each rank sends the tiles it owns -- 1/N of the image -- to rank 0).
 
 value = rays (the reference's own `raysTraced` definition: primary samples + occlusion rays + scatter rays,
 path_tracer.cpp:62,219,242,276) of the whole job / wall time of the K steps, max over ranks.
@@ -192,7 +193,14 @@ def main():
     tracer.upload_scene(scene)
     tracer.set_camera(camera)
 
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")  # this rank's framebuffer (its tiles; zeros elsewhere)
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")  # this rank's framebuffer (rank 0's receives the gathered image)
+    if use_dist:
+        # the library's own RCCL communicator: rank 0 makes the id, its 128 bytes travel over torch.distributed
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(prt_amd.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        tracer.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
     # a non-default torch stream: the kernel is launched on it through the C-ABI, the RCCL gather is ordered behind
     # it, and the C-ABI's HIP events are recorded on it
     tstream = torch.cuda.Stream()
@@ -200,13 +208,10 @@ def main():
     stream = tstream.cuda_stream
 
     def step():
-        if use_dist:
-            fb.zero_()  # rank 0's buffer holds the previous step's gathered image: the sum-reduce needs zeros where a rank owns nothing
         tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure, rank=rank, nranks=world)
         if use_dist:
-            # the only exchange: image gather.  Every pixel is non-zero on exactly one rank, so a sum-reduce to rank 0
-            # assembles the image exactly (x + 0 == x); 25 MB at 1080p over xGMI.
-            prt_amd.gather_image(fb, dst=0)
+            # the only exchange: every rank's owned tiles (25 MB / N at 1080p) to rank 0 over RCCL, de-interleaved there
+            tracer.gather_rccl(d_rgb=fb.data_ptr(), root=0, stream=stream)
 
     def sync():
         if use_dist:
@@ -255,7 +260,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "description": describe, "width": W, "height": H, "spp": spp, "max_depth": depth,
                        "seed": args.seed, "rays_per_step": int(rays_per_step), "occlusion_rays_per_step": int(occl_per_step),
-                       "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL sum-reduce image gather" if world > 1
+                       "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL send/recv image gather of {tracer.gather_payload_bytes()} B per rank" if world > 1
                        else "one GPU", "device": name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_rate, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "kernel": "wavefront pipeline of one frame: shade_kernel + trace_kernel<0..3>, (spp/8)*(1+depth)+1 iterations", "kernel_ms": kernel_ms,

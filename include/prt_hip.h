@@ -31,6 +31,7 @@ extern "C" {
 #define PRT_HIP_ELAUNCH (-4)
 #define PRT_HIP_ESTATE (-5)    /* scene or camera not uploaded */
 #define PRT_HIP_ESTACK (-6)    /* traversal stack deeper than 64 entries (reference asserts, bvh.cpp:552) */
+#define PRT_HIP_ECOMM (-7)     /* RCCL: library not found or a communicator call failed */
 
 #define PRT_HIP_MAX_BVH 8
 
@@ -165,10 +166,29 @@ int prt_hip_render_gbuffer(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t 
 /* copies the rectangle (inclusive) of the context's framebuffer into a host image of the camera's size */
 int prt_hip_download(prt_hip_ctx* ctx, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 float* prt_hip_framebuffer(prt_hip_ctx* ctx); /* device pointer, width*height*3 floats */
-/* Single-process multi-GPU hosts: n contexts, context i having rendered its share of the SAME rectangle with
- * params.rank = i, params.nranks = n into its own framebuffer (d_rgb = NULL).  Assembles the image in rgb_host (camera-sized):
- * every pixel of the rectangle is taken from the context that owns its tile.  (One process per GPU -- the arrangement bench.py
- * uses -- gathers with one RCCL reduce instead: prt_amd.gather_image.) */
+/* ---- image gather: the ONE exchange of the multi-GPU path.  The reference has none (one process, one
+ * Image, main.cpp:107-190); tiles are dealt to ranks by tile id % nranks (prt_render_params), every rank renders the
+ * tiles it owns into its own camera-sized framebuffer and the owned tiles are moved to the root: each rank packs them
+ * tile-major (1/nranks of the image: 3.1 MB at 1080p with 8 ranks), the packed tiles travel, the root de-interleaves them
+ * into its frame.  No reduction, no full-frame traffic, nothing to zero between frames. ---- */
+#define PRT_HIP_COMM_ID_BYTES 128
+/* One process per GPU (RCCL over xGMI; librccl is loaded on first use).  Rank 0 makes an id and ships its 128 bytes to the
+ * other ranks over any host channel; then EVERY rank calls prt_hip_comm_init (collective).  A host that already owns an
+ * ncclComm_t for these ranks hands it over with prt_hip_comm_adopt instead (the library never destroys an adopted one). */
+int prt_hip_comm_unique_id(void* id128);
+int prt_hip_comm_init(prt_hip_ctx* ctx, const void* id128, int rank, int nranks);
+int prt_hip_comm_adopt(prt_hip_ctx* ctx, void* ncclComm);
+int prt_hip_comm_destroy(prt_hip_ctx* ctx);
+/* Collective, after prt_hip_render(..., params.rank = the communicator's rank, params.nranks = its size, d_rgb, stream) on every
+ * rank: grouped ncclSend (owners) / ncclRecv (root), so that each link into the root carries one peer's tiles, then the
+ * de-interleave kernel on the root.  d_rgb / stream as in prt_hip_render (the same buffer the render wrote); afterwards the
+ * root's buffer holds the whole image, the other ranks' buffers are unchanged. */
+int prt_hip_gather_rccl(prt_hip_ctx* ctx, float* d_rgb, int root, void* stream);
+/* bytes the context's rank contributes to a gather of its last render (what travels over xGMI) */
+int prt_hip_gather_payload_bytes(prt_hip_ctx* ctx, uint64_t* bytes);
+/* One process driving several contexts: context i has rendered with params.rank = i, params.nranks = n into its own
+ * framebuffer (d_rgb = NULL).  The same pack and de-interleave kernels with device-to-device copies in between assemble the
+ * image in context 0's framebuffer; the rectangle of it is then copied to rgb_host (camera-sized). */
 int prt_hip_gather(prt_hip_ctx* const* ctxs, int n, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1);
 int prt_hip_get_stats(prt_hip_ctx* ctx, prt_hip_stats* stats);
 

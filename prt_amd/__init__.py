@@ -104,6 +104,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 EXPORTS = [
     "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
     "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_render_gbuffer", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
+    "prt_hip_comm_unique_id", "prt_hip_comm_init", "prt_hip_comm_adopt", "prt_hip_comm_destroy", "prt_hip_gather_rccl", "prt_hip_gather_payload_bytes",
     "prt_hip_get_stats",
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
     "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
@@ -160,6 +161,12 @@ def _load(path, with_test_entry_points):
     L.prt_hip_download.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.prt_hip_render_gbuffer.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, vp, vp]
     L.prt_hip_gather.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.prt_hip_comm_unique_id.argtypes = [vp]
+    L.prt_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.prt_hip_comm_adopt.argtypes = [vp, vp]
+    L.prt_hip_comm_destroy.argtypes = [vp]
+    L.prt_hip_gather_rccl.argtypes = [vp, vp, C.c_int, vp]
+    L.prt_hip_gather_payload_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.prt_hip_framebuffer.restype = vp
     L.prt_hip_framebuffer.argtypes = [vp]
     L.prt_hip_get_stats.argtypes = [vp, C.POINTER(HipStats)]
@@ -439,6 +446,21 @@ class PathTracer:
         W, H = self._camera.width, self._camera.height
         return self.trace_block(0, 0, W - 1, H - 1, samples, **kw)
 
+    # ---- multi-process image gather over RCCL (include/prt_hip.h "image gather")
+    def comm_init(self, unique_id, rank, nranks):
+        """Collective: every rank calls it with rank 0's id (comm_unique_id(), shipped over any host channel)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.prt_hip_comm_init(self._ctx, buf, rank, nranks), "prt_hip_comm_init")
+
+    def gather_rccl(self, d_rgb=None, root=0, stream=None):
+        """Collective: moves the tiles every rank owns (1/nranks of the image) to `root` and de-interleaves them there."""
+        self._chk(self._L.prt_hip_gather_rccl(self._ctx, d_rgb, root, stream), "prt_hip_gather_rccl")
+
+    def gather_payload_bytes(self):
+        n = C.c_uint64()
+        self._chk(self._L.prt_hip_gather_payload_bytes(self._ctx, C.byref(n)), "prt_hip_gather_payload_bytes")
+        return n.value
+
     def stats(self):
         st = HipStats()
         self._chk(self._L.prt_hip_get_stats(self._ctx, C.byref(st)), "prt_hip_get_stats")
@@ -562,6 +584,13 @@ def save_ppm(path, rgb, tonemap=True):
     _check(lib().prt_host_save_ppm(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p), int(tonemap)), "prt_host_save_ppm")
 
 
+def comm_unique_id():
+    """128 bytes naming a new RCCL communicator (rank 0 calls this and broadcasts the bytes)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().prt_hip_comm_unique_id(buf), "prt_hip_comm_unique_id")
+    return buf.raw
+
+
 def gather_contexts(tracers, x0, y0, x1, y1):
     """prt_hip_gather: one process driving several contexts (tracer i rendered the rectangle with rank=i, nranks=len(tracers)
     into its own framebuffer); returns the assembled (H, W, 3) image."""
@@ -572,10 +601,54 @@ def gather_contexts(tracers, x0, y0, x1, y1):
     return img
 
 
-def gather_image(framebuffer, dst=0):
-    """The path's only exchange: assemble the image on rank `dst`.  Every pixel is non-zero on exactly one rank (the
-    others never touch it in their zero-initialised framebuffer), so a sum-reduce reproduces it exactly (x + 0 == x).
-    `framebuffer` is a torch tensor (CUDA -> RCCL over xGMI with backend "nccl"; CPU -> gloo in the tests)."""
+def owned_tile_ids(width, height, rank, nranks, tile=16):
+    """Tile ids rank, rank + nranks, ... of the image's tile grid: the order of the tiles in a rank's packed buffer."""
+    total = ((width + tile - 1) // tile) * ((height + tile - 1) // tile)
+    return np.arange(rank, total, nranks, dtype=np.int64)
+
+
+def pack_tiles(image, rank, nranks, tile=16):
+    """Host mirror of the library's pack kernel (prt_gather.hip): the tiles `rank` owns, tile-major, (n, tile, tile, 3);
+    pixels beyond the image's edge are zero."""
+    H, W, _ = image.shape
+    tiles_x = (W + tile - 1) // tile
+    ids = owned_tile_ids(W, H, rank, nranks, tile)
+    out = np.zeros((len(ids), tile, tile, 3), dtype=np.float32)
+    for q, t in enumerate(ids):
+        x0, y0 = int(t % tiles_x) * tile, int(t // tiles_x) * tile
+        crop = image[y0:y0 + tile, x0:x0 + tile]
+        out[q, :crop.shape[0], :crop.shape[1]] = crop
+    return out
+
+
+def unpack_tiles(image, packed, rank, nranks, tile=16):
+    """Host mirror of the de-interleave kernel: writes rank's packed tiles into `image` (in place)."""
+    H, W, _ = image.shape
+    tiles_x = (W + tile - 1) // tile
+    for q, t in enumerate(owned_tile_ids(W, H, rank, nranks, tile)):
+        x0, y0 = int(t % tiles_x) * tile, int(t // tiles_x) * tile
+        h, w = min(tile, H - y0), min(tile, W - x0)
+        image[y0:y0 + h, x0:x0 + w] = packed[q, :h, :w]
+    return image
+
+
+def gather_image_host(framebuffer, rank, nranks, dst=0, tile=16):
+    """The gather's data movement on HOST tensors over torch.distributed point-to-point (gloo in the CPU tests): every rank
+    sends the tiles it owns, packed as the device packs them, to `dst`, which de-interleaves them -- the same ownership
+    rule, tile order and payload as prt_hip_gather_rccl, without the GPU.  `framebuffer` is a (H, W, 3) float32 numpy array."""
+    import torch
     import torch.distributed as dist
-    dist.reduce(framebuffer, dst=dst, op=dist.ReduceOp.SUM)
+    H, W, _ = framebuffer.shape
+    if rank != dst:
+        mine = pack_tiles(framebuffer, rank, nranks, tile)
+        if mine.size:
+            dist.send(torch.from_numpy(mine), dst=dst)
+        return framebuffer
+    for r in range(nranks):
+        n = len(owned_tile_ids(W, H, r, nranks, tile))
+        if r == dst or n == 0:
+            continue
+        buf = torch.empty((n, tile, tile, 3), dtype=torch.float32)
+        dist.recv(buf, src=r)
+        unpack_tiles(framebuffer, buf.numpy(), r, nranks, tile)
     return framebuffer

@@ -11,12 +11,13 @@ TEST_LIB = os.path.join(LIB_DIR, "libprt_hip_test.so")  # same sources + -DPRT_T
 
 SOURCES = [
     "prt_kernels.hip",
+    "prt_gather.hip",
     "host/prt_host.cpp",
     "host/prt_bvh.cpp",
     "host/prt_models.cpp",
     "host/prt_host_capi.cpp",
 ]
-HEADERS = ["prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc", "../../include/prt_hip.h",
+HEADERS = ["prt_internal.h", "prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc", "../../include/prt_hip.h",
            "../../include/prt_host.h", "../../include/prt_hip_test.h"]
 
 # -ffp-contract=off: the reference's object code has no FMA, and results must match it bit for bit.
@@ -24,7 +25,7 @@ HEADERS = ["prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc
 # -fno-slp-vectorize: the SLP vectoriser's v_pk_* pairs cost more v_mov shuffling than they save (C3 frame 591 -> 551 ms,
 # measured); the node step keeps its hand-packed (lo, hi) slab pairs, whose operands come out of the loads already paired.
 # (What bounds the trace kernels is in DESIGN.md section 4, from the counter files under profiles/.)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread", "-ldl",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

@@ -21,6 +21,7 @@
 
 #include "../../include/prt_hip.h"
 #include "prt_device.h"
+#include "prt_internal.h"
 
 // ============================================================================ device: group helpers
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -125,21 +126,6 @@ struct Surf5 { // what moves between slots at a compaction
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 #define PRT_QSHARDS 16
-#ifndef PRT_SHADE_WAVES
-#define PRT_SHADE_WAVES 7 // waves per SIMD the shade kernel is compiled for (C3: 8: 514 ms, 7: 507, 6 and 5: 514, 4: 523)
-#endif
-#ifndef PRT_TRACE_BPC
-#define PRT_TRACE_BPC 4 // persistent blocks per CU and trace kernel
-#endif
-#ifndef PRT_SIDE_STREAMS
-#define PRT_SIDE_STREAMS 1 // side streams per pipeline for the three smaller trace kernels (1 or 3)
-#endif
-#ifndef PRT_PARTS
-#define PRT_PARTS 2 // independent pipelines a pass is dealt to
-#endif
-#define PRT_WORK_WORDS 128 // queue counters of one pipeline (4 + Q_COUNT * PRT_QSHARDS used)
-#define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
-#define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
 #define SLOT_LIGHT_SET 4u
@@ -977,22 +963,18 @@ __global__ void camera_kernel(DevCamera cam, uint32_t x, uint32_t y, uint32_t st
 
 // ============================================================================ host side of the C-ABI
 namespace {
-
 thread_local std::string g_err;
-
-int fail(int code, const std::string& msg)
+} // namespace
+int prt_fail(int code, const std::string& msg)
 {
     g_err = msg;
     return code;
 }
+const std::string& prt_last_error_string() { return g_err; }
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(e_ == hipErrorOutOfMemory ? PRT_HIP_ENOMEM : PRT_HIP_ENODEVICE,                 \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
-    } while (0)
+namespace {
+
+int fail(int code, const std::string& msg) { return prt_fail(code, msg); }
 
 struct HVec3 { float x, y, z; };
 inline HVec3 hsub(HVec3 a, HVec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -1014,47 +996,6 @@ inline void hsafe_normalize2(float x, float y, float* ox, float* oy) // vecmath.
 inline float ubits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 } // namespace
-
-#define PRT_TIMING_RING 32
-struct prt_hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // Timing: a fixed ring of event pairs, one pair per render launch.  When the ring is full the oldest launches are folded
-    // into accMs (they have long finished), so a caller that renders in a loop without reading the stats holds no more than
-    // PRT_TIMING_RING pairs.
-    hipEvent_t evT0[PRT_TIMING_RING] = {}, evT1[PRT_TIMING_RING] = {};
-    uint32_t ringUsed = 0;
-    double accMs = 0.0, lastMs = 0.0;
-    uint64_t accLaunches = 0;
-    int computeUnits = 0;
-    std::string name;
-    // scene
-    bool haveScene = false, haveCamera = false;
-    DevScene sc{};
-    DevCamera cam{};
-    std::vector<void*> sceneAllocs;
-    // render resources
-    float* fb = nullptr;
-    size_t fbPixels = 0;
-    uint32_t* work = nullptr; // Q_COUNT queue counters
-    unsigned long long* counters = nullptr;
-    // PRT_PARTS independent pipelines (a pass dealt tile by tile) run side by side, each on a main stream (shade, scatter
-    // trace) and a side stream (the other three trace kernels): stream, aux[0] | aux[1], aux[2] | ...  Two pipelines = four
-    // streams = the four hardware queues a HIP process gets by default (measured on C3, whole frame / one rank's share of
-    // 8: 2 pipelines 588 / 102 ms; 3: 590-660 / 110-138; 4: 595-657 / 106-135 depending on GPU_MAX_HW_QUEUES).
-    hipStream_t aux[(1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1] = {};
-    hipEvent_t evFork[PRT_PARTS] = {}, evJoin[PRT_PARTS * PRT_SIDE_STREAMS] = {};
-    hipEvent_t evStart = nullptr, evDone[PRT_PARTS] = {}; // pipelines 1.. against the main stream, per pass
-    hipEvent_t evIn = nullptr, evOut = nullptr; // order the pipeline against a caller's stream
-    void* wfBuffer = nullptr; // wavefront state + queues of one pass
-    size_t wfBytes = 0;
-    uint32_t wfGroups = 0;
-    uint32_t* spill = nullptr;
-    uint32_t spillThreads = 0;
-    uint32_t lastRank = 0, lastNranks = 0, lastTile = 0; // of the last render (prt_hip_gather)
-    int blocksPerCU = 0;
-    bool timed = false;
-};
 
 template <typename T>
 static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
@@ -1152,7 +1093,7 @@ int prt_hip_create(int device, prt_hip_ctx** out)
     c->device = device;
     int rc = create_resources(c);
     if (rc != PRT_HIP_OK) {
-        std::string why = g_err; // prt_hip_destroy makes HIP calls of its own
+        std::string why = prt_last_error_string(); // prt_hip_destroy makes HIP calls of its own
         prt_hip_destroy(c);      // frees whatever was created before the failure
         return fail(rc, why);
     }
@@ -1178,6 +1119,7 @@ void prt_hip_destroy(prt_hip_ctx* c)
     if (c->counters) (void)hipFree(c->counters);
     if (c->spill) (void)hipFree(c->spill);
     if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+    prt_gather_release(c);
     for (int k = 0; k < PRT_TIMING_RING; k++) {
         if (c->evT0[k]) (void)hipEventDestroy(c->evT0[k]);
         if (c->evT1[k]) (void)hipEventDestroy(c->evT1[k]);
@@ -1485,6 +1427,7 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env
     }
     if (need > c->wfBytes) {
         if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+    prt_gather_release(c);
         c->wfBuffer = nullptr;
         c->wfBytes = 0;
         HIP_TRY(hipMalloc(&c->wfBuffer, need));
@@ -1669,6 +1612,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     c->lastRank = p->rank;
     c->lastNranks = p->nranks;
     c->lastTile = p->tileSize;
+    c->lastTarget = d_rgb;
     if (caller) {
         HIP_TRY(hipEventRecord(c->evOut, s));
         HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
@@ -1736,40 +1680,6 @@ int prt_hip_download(prt_hip_ctx* c, float* rgb_host, uint32_t x0, uint32_t y0, 
     size_t off = ((size_t)y0 * W + x0) * 3;
     HIP_TRY(hipMemcpy2D(rgb_host + off, (size_t)W * 3 * sizeof(float), c->fb + off, (size_t)W * 3 * sizeof(float), rowBytes,
                         y1 - y0 + 1, hipMemcpyDeviceToHost));
-    return PRT_HIP_OK;
-}
-
-int prt_hip_gather(prt_hip_ctx* const* ctxs, int n, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
-{
-    if (!ctxs || n <= 0 || !rgb_host) return fail(PRT_HIP_EINVAL, "bad argument");
-    for (int i = 0; i < n; i++) {
-        if (!ctxs[i] || !ctxs[i]->fb) return fail(PRT_HIP_ESTATE, "a context has nothing rendered into its framebuffer");
-        if (ctxs[i]->lastNranks != (uint32_t)n || ctxs[i]->lastRank != (uint32_t)i)
-            return fail(PRT_HIP_ESTATE, "context i must have rendered with rank = i, nranks = n");
-        if (ctxs[i]->cam.width != ctxs[0]->cam.width || ctxs[i]->cam.height != ctxs[0]->cam.height || ctxs[i]->lastTile != ctxs[0]->lastTile)
-            return fail(PRT_HIP_ESTATE, "contexts disagree on image size or tile size");
-    }
-    const uint32_t W = ctxs[0]->cam.width, H = ctxs[0]->cam.height, T = ctxs[0]->lastTile;
-    if (x1 < x0 || y1 < y0 || x1 >= W || y1 >= H) return fail(PRT_HIP_EINVAL, "pixel rectangle outside the image");
-    const uint32_t tilesX = (W + T - 1) / T;
-    const size_t rowFloats = (size_t)(x1 - x0 + 1) * 3;
-    std::vector<float> part((size_t)(y1 - y0 + 1) * rowFloats);
-    for (int i = 0; i < n; i++) {
-        prt_hip_ctx* c = ctxs[i];
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy2D(part.data(), rowFloats * sizeof(float), c->fb + ((size_t)y0 * W + x0) * 3, (size_t)W * 3 * sizeof(float),
-                            rowFloats * sizeof(float), y1 - y0 + 1, hipMemcpyDeviceToHost));
-        for (uint32_t y = y0; y <= y1; y++) {
-            const float* src = &part[(size_t)(y - y0) * rowFloats];
-            float* dst = rgb_host + ((size_t)y * W + x0) * 3;
-            for (uint32_t x = x0; x <= x1;) {
-                const uint32_t tile = (y / T) * tilesX + x / T, xe = std::min<uint32_t>(x1, (x / T + 1) * T - 1);
-                if (tile % (uint32_t)n == (uint32_t)i) memcpy(dst + (size_t)(x - x0) * 3, src + (size_t)(x - x0) * 3, (size_t)(xe - x + 1) * 3 * sizeof(float));
-                x = xe + 1;
-            }
-        }
-    }
     return PRT_HIP_OK;
 }
 

@@ -506,6 +506,34 @@ def test_single_process_gather_of_several_contexts(tracer, c1):
             t.close()
 
 
+def test_rccl_gather_single_rank_communicator(tracer, c1):
+    """prt_hip_gather_rccl through a real RCCL communicator of ONE rank (all a 1-GPU box allows: RCCL refuses two ranks on one
+    device): librccl is found and loaded, ncclCommInitRank / grouped send-recv bookkeeping / stream ordering run, the
+    root's image is left exactly as rendered, and the payload is the rank's share of the tile-padded image.  The >1-rank
+    data movement (ownership, tile order, de-interleave) is covered by the same kernels in
+    test_single_process_gather_of_several_contexts and by the gloo tests on host tensors."""
+    scene, camera, desc = c1
+    t = prt_amd.PathTracer(device=0, max_depth=4, seed=12345)
+    try:
+        t.upload_scene(scene)
+        t.set_camera(camera)
+        with pytest.raises(prt_amd.PrtError, match="no communicator"):
+            t.gather_rccl()
+        t.comm_init(prt_amd.comm_unique_id(), 0, 1)
+        t.render_async(0, 0, 511, 299, 8)
+        before = _download(t, np.zeros((512, 512, 3), dtype=np.float32))
+        t.gather_rccl(root=0)
+        after = _download(t, before)
+        assert after.tobytes() == before.tobytes() and np.abs(after[:300]).sum() > 0
+        assert t.gather_payload_bytes() == 32 * 32 * 256 * 12
+        t.render_async(0, 0, 511, 299, 8, rank=1, nranks=2)
+        with pytest.raises(prt_amd.PrtError, match="rank/nranks"):
+            t.gather_rccl(root=0)  # rendered as rank 1 of 2, the communicator has one rank
+        assert t.gather_payload_bytes() == 16 * 32 * 256 * 12
+    finally:
+        t.close()
+
+
 def test_full_size_c3_properties(tracer):
     """BASELINE config 3 as bench.py runs it (Sponza-class stand-in, 262 k triangles, 1920x1080, 64 spp, depth 8), checked
     through size-independent properties: repeatable, independent of how the image is cut into launches and ranks

@@ -1,6 +1,8 @@
-"""world_size-2 test of the multi-GPU host path on CPU (gloo): tile ownership + the image gather.  The kernels cannot
-run here, so each rank fills its own tiles with the ORACLE's pixels (the checker standing in for the GPU), exactly as
-bench.py's ranks fill theirs with prt_hip_render(rank, nranks); rank 0 must end up with the single-rank image bit for bit."""
+"""world_size-2 (and 3) test of the multi-GPU host path on CPU (gloo): tile ownership + the image gather.  The kernels
+cannot run here, so each rank fills its own tiles with the ORACLE's pixels (the checker standing in for the GPU), exactly as
+bench.py's ranks fill theirs with prt_hip_render(rank, nranks), and poisons every pixel it does not own; the owned tiles are
+packed tile-major, sent to rank 0 and de-interleaved there -- the data movement of prt_hip_gather_rccl (prt_gather.hip)
+on host tensors.  Rank 0 must end up with the single-rank image bit for bit."""
 import os
 import socket
 import sys
@@ -38,9 +40,10 @@ def _worker(rank, world, port, out_path):
                 x1, y1 = min(tx + 15, W - 1), min(ty + 15, H - 1)
                 crop, _ = scene.trace_block(tx, ty, x1, y1, spp)
                 fb[ty:y1 + 1, tx:x1 + 1] = crop
-    assert (fb[~own] == 0).all()
-    t = torch.from_numpy(fb)
-    prt_amd.gather_image(t, dst=0)
+    fb[~own] = np.float32(-7.0)  # nothing a rank does not own may reach the image: the gather moves owned tiles only
+    payload = prt_amd.pack_tiles(fb, rank, world).nbytes
+    assert payload == len(prt_amd.owned_tile_ids(W, H, rank, world)) * 16 * 16 * 12  # 1/world of the (tile-padded) image
+    t = torch.from_numpy(prt_amd.gather_image_host(fb, rank, world, dst=0))
     # every pixel has exactly one owner
     cover = torch.from_numpy(own.astype(np.int32))
     dist.all_reduce(cover)
@@ -52,9 +55,10 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_tile_sharding_and_gather(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_sharding_and_gather(tmp_path, world):
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     got, ref = np.load(out)
     assert got.tobytes() == ref.tobytes()
 
@@ -67,3 +71,16 @@ def test_owned_pixel_mask_partitions_the_image():
         counts = [int(prt_amd.owned_pixel_mask(w, h, r, n).sum()) for r in range(n)]
         if w * h >= 16 * 16 * n * 4:
             assert max(counts) - min(counts) <= 4 * 256  # round-robin keeps the shares within a few tiles
+
+
+def test_pack_and_unpack_are_inverse_and_tile_major():
+    import prt_amd
+    rng = np.random.default_rng(3)
+    for (w, h, n) in ((72, 40, 3), (1920, 1080, 8), (16, 16, 2), (33, 17, 5)):
+        img = rng.random((h, w, 3), dtype=np.float32)
+        out = np.full_like(img, -1)
+        for r in range(n):
+            p = prt_amd.pack_tiles(img, r, n)
+            assert p.shape[0] == len(prt_amd.owned_tile_ids(w, h, r, n))
+            prt_amd.unpack_tiles(out, p, r, n)
+        assert out.tobytes() == img.tobytes()
