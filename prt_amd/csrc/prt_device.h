@@ -723,6 +723,27 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 __device__ __forceinline__ bool ref_is_internal(uint32_t ref) { return !(ref & PRT_REF_LEAF); }
 __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & PRT_REF_LEAF) && ref != PRT_REF_NONE; }
 
+// Step phase of the wave loops: a step is one internal node or one triangle.  Each round the larger of the two groups of
+// lanes steps (the other waits: SIMD lanes that cannot share an instruction stream), until PRT_IDLE_BREAK lanes have nothing
+// to step on -- their ray is finished or moves to the next BVH -- and the wave goes back to its refill point to serve them.
+template <int MODE, bool COUNT, class STK>
+__device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, bool active, const STK& st, Traffic& tr, uint32_t& overflow)
+{
+    for (;;) {
+        const bool onNode = active && ref_is_internal(T.ref);
+        const bool onLeaf = active && ref_is_leaf(T.ref);
+        const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
+        if (nNode + nLeaf == 0u) break;
+        const bool doNode = nNode >= nLeaf; // weighting either side, or staying with one kind while it has 16-32 lanes, measured slower
+        if (doNode) {
+            if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+        } else {
+            if (onLeaf) tracer_tri<MODE, COUNT>(sc, T, st, tr);
+        }
+        if ((uint32_t)__popcll(__ballot(active && T.ref == PRT_REF_NONE)) >= PRT_IDLE_BREAK) break;
+    }
+}
+
 // The wave-level loop: every lane owns one ray at a time and takes a new one from `src` as soon as its own is
 // finished (persistent lanes, wave-aggregated claim: ballot + popcount + one atomic per wave).  "while-while": all
 // lanes that stand on an internal node step together until every lane stands on a leaf (or has nothing), then the
@@ -800,22 +821,7 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                 active = false;
             }
         }
-        // Step phase: a step is one internal node or one triangle.  Each round the larger of the two groups of lanes steps
-        // (the other waits: SIMD lanes that cannot share an instruction stream), until PRT_IDLE_BREAK lanes have nothing
-        // to step on -- their ray is finished or moves to the next BVH -- and the wave goes back to the top to serve them.
-        for (;;) {
-            const bool onNode = active && ref_is_internal(T.ref);
-            const bool onLeaf = active && ref_is_leaf(T.ref);
-            const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
-            if (nNode + nLeaf == 0u) break;
-            const bool doNode = nNode >= nLeaf; // weighting either side, or staying with one kind while it has 16-32 lanes, measured slower
-            if (doNode) {
-                if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
-            } else {
-                if (onLeaf) tracer_tri<MODE, COUNT>(sc, T, st, tr);
-            }
-            if ((uint32_t)__popcll(__ballot(active && T.ref == PRT_REF_NONE)) >= PRT_IDLE_BREAK) break;
-        }
+        trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
 }
 

@@ -1,0 +1,759 @@
+// prt_frame.h -- the frame kernel: ONE persistent launch renders a pixel rectangle (or a rank's tile share of it).
+//
+// Scheduling (DESIGN.md "Kernels").  The reference traces a pixel as samples/8 packets that share one xorshift32 stream,
+// each packet a chain of 1 + maxDepth (shade -> trace) rounds (path_tracer.cpp:57-75, 124-301): per pixel that is a strictly
+// sequential chain of (samples/8)*(1+maxDepth)+1 rounds, but pixels are independent.  So every workgroup keeps its OWN pool
+// of pixel groups in flight and walks each group along its chain at the group's own pace -- there is no grid-wide step and
+// no host loop:
+//
+//   pool      PRT_POOL_CHUNKS rows of 64 pixel groups (a group = the 8 path slots of one pixel).  A row is claimed from a
+//             global cursor (64 consecutive tile-major work items = a quarter of a 16x16 tile) when all its groups are done.
+//   pending   one LDS word per group: rays of the group still in flight.  0 = ready for its next shade round.
+//   queues    four ray queues per block (primary packet rays, scatter rays, packet / single occlusion rays): rings in HBM that
+//             only this block touches, head and tail in LDS.  An entry names the owner slot; the ray is rebuilt from its state.
+//   roles     every wave alternates: SHADE (one wave at a time, LDS lock) sweeps the pending words, runs the bounce of up to 8
+//             ready groups per pass (8 lanes per group, wave ballot / popcount compaction and prefix-counted RNG stepping as
+//             before), emits the next rays and sets pending = rays emitted;  TRACE takes the fullest queue and walks its rays
+//             with persistent lanes (a lane refills from the queue the moment its ray finishes); a finished ray's lane stores
+//             the hit and decrements the group's pending word.
+//
+// Everything a block shares lives on ONE CU: the hand-offs are LDS atomics plus workgroup-scope release/acquire (global
+// stores drained with s_waitcnt vmcnt(0) before the LDS word that publishes them; waves of a workgroup share the CU's L1), so
+// no agent-scope fence, no cross-XCD traffic and no inter-workgroup dependency exists -- a block that starts late or runs
+// alone still completes.  The only global words are the row cursor, the statistics and the watchdog flag.
+#pragma once
+
+#ifndef PRT_POOL_CHUNKS
+#define PRT_POOL_CHUNKS 8 // rows of 64 pixel groups a block keeps in flight
+#endif
+#ifndef PRT_FRAME_WAVES
+#define PRT_FRAME_WAVES 7 // waves per SIMD the frame kernel is compiled for
+#endif
+#ifndef PRT_SHADE_MIN
+#define PRT_SHADE_MIN 16u // ready groups that make a wave at a decision point take the shade role
+#endif
+#ifndef PRT_DRAIN_READY
+#define PRT_DRAIN_READY 192u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
+#endif
+#define PRT_CHUNK 64u
+#define PRT_POOL_GROUPS (PRT_POOL_CHUNKS * PRT_CHUNK)
+#define PRT_POOL_SLOTS (PRT_POOL_GROUPS * 8u) // capacity of a block's ray queue per mode: one ray per slot and mode at most
+#define PEND_DONE 0xffffffffu
+#define PRT_NONE 0xffffffffu
+
+struct FrameArgs {
+    DevScene sc;
+    DevCamera cam;
+    prt_render_params p;
+    uint32_t x0, y0, x1, y1;
+    uint32_t tilesXImage;
+    uint32_t rtx0, rty0, rtnx, rtny;
+    uint32_t fullWidth, firstOwned;
+    uint32_t totalWork;   // pixel groups (tile-major work items) of the launch
+    uint32_t totalChunks; // rows of 64 work items
+    uint32_t rowsPerBlock; // rows a block may hold at a time (<= PRT_POOL_CHUNKS; fewer when the launch is small)
+    float* rgb;
+    unsigned long long* counters; // PRT_STAT_SHARDS copies of: rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
+    uint32_t* ctrl;               // [0] row cursor, [1] watchdog flag
+    // per pool group (block * PRT_POOL_GROUPS + i)
+    uint32_t* gRng;
+    uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20 | alive at depth 0 << 24
+    uint32_t* gPixel; // x | y << 16, 0xffffffff = no pixel (outside the rectangle / not this rank's tile)
+    float4* gColor;
+    // per pool slot (8 per group)
+    float4* S0; // pos.xyz, bits(material of the surface the path stands on)
+    float4* S1; // shading normal xyz, bits(slot flags)
+    float4* S2; // direction of the ray in flight (primary or scatter) xyz
+    float4* S3; // beta.xyz
+    float4* S4; // result.xyz -- belongs to the SLOT, not the path
+    float4* S5; // environment light only: lightDir[slot]
+    float4* S6; //                         lightIntensity[slot]
+    float4* hitA;   // t i j k
+    uint2* hitB;    // primId meshId
+    uint32_t* occl; // 1 = occluded
+    uint32_t* qE;   // [block][Q_COUNT][PRT_POOL_SLOTS]: owner slot within the block | reverseBits << 26 | lightSet << 29
+    uint32_t* spill;
+    uint32_t spillStride;
+};
+
+struct BlockState { // LDS
+    uint32_t pending[PRT_POOL_GROUPS];
+    uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
+    uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
+    uint32_t lock;      // shade role
+    uint32_t ready;     // groups with pending == 0 (a hint for the role decision, not a correctness word)
+    uint32_t live;      // groups in the pool that are not done
+    uint32_t exhausted; // the global cursor has no more rows
+    uint32_t abort;
+};
+
+struct WaveStats {
+    uint32_t rays, occl, px;
+};
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_ld_acq(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// every global store of this wave has completed and is visible to the other waves of the workgroup (same CU, same L1)
+__device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// Pixel of work item w (tile-major order, row-major inside a tile, main.cpp:132-138); 0xffffffff when the item lies outside
+// the rectangle or in a tile another rank owns.
+__device__ __forceinline__ uint32_t work_item_pixel(const FrameArgs& A, uint32_t w)
+{
+    const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
+    const uint32_t tq = w / tile2, pix = w - tq * tile2;
+    uint32_t gt;
+    bool ok = true;
+    if (A.fullWidth) {
+        gt = A.firstOwned + tq * A.p.nranks;
+    } else {
+        uint32_t qx = tq % A.rtnx, qy = tq / A.rtnx;
+        gt = (A.rty0 + qy) * A.tilesXImage + (A.rtx0 + qx);
+        ok = (gt % A.p.nranks) == A.p.rank;
+    }
+    uint32_t tx = gt % A.tilesXImage, ty = gt / A.tilesXImage;
+    uint32_t x = tx * tile + pix % tile, y = ty * tile + pix / tile;
+    if (x < A.x0 || x > A.x1 || y < A.y0 || y > A.y1) ok = false;
+    return ok ? (x | (y << 16)) : 0xffffffffu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- shade
+// One shade round of up to 8 pixel groups (lanes 8j..8j+7 = the 8 path slots of group j).  P = the group's index into the
+// pool state, PRT_NONE for lanes without a group.  Consumes the hits of the group's last rays, runs the bounce of
+// path_tracer.cpp:124-293 and appends the next rays to the block's queues (`tails` = the queue tails, owned by the caller,
+// who holds the shade lock and publishes them).  Returns, in every lane of the group, the group's new pending word: the
+// number of rays emitted, or PEND_DONE when the pixel has been written.
+template <bool COUNT, bool ENV>
+__device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, uint32_t poolLocal, uint32_t (&tails)[Q_COUNT], uint32_t* blockQ,
+                                               WaveStats& ws, Traffic& tr)
+{
+    const uint32_t lane = threadIdx.x & 63u, slot = lane & 7u, gbase = lane & ~7u;
+    const bool inRange = P != PRT_NONE;
+    const uint32_t g = inRange ? P : 0u;
+    const uint32_t gs = g * 8u + slot;
+    const DevScene& sc = A.sc;
+    const DevCamera& cam = A.cam;
+    const uint32_t samples = A.p.samples, maxDepth = A.p.maxDepth, rrDepth = A.p.rrDepth, packets = samples / 8u;
+    const float kPi = 3.14159265358979323846f;
+    const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
+    const uint32_t lowerMask = (1u << slot) - 1u;
+
+    uint32_t info = inRange ? A.gInfo[g] : ((uint32_t)PH_DONE << 20);
+    uint32_t phase = (info >> 20) & 0xfu, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
+    uint32_t alive0 = (info >> 24) & 0xfu; // slots that have held a path in this packet: the others' result is still 0
+    const uint32_t aliveAtEntry = (phase == PH_WAIT_BOUNCE) ? alive : 0u;
+    uint32_t rng = 0, pixel = 0xffffffffu;
+    Vec3 color = mk3(0, 0, 0);
+    if (inRange) {
+        rng = A.gRng[g];
+        pixel = A.gPixel[g];
+        float4 c = A.gColor[g];
+        color = mk3(c.x, c.y, c.z);
+    }
+    const uint32_t x = pixel & 0xffffu, y = pixel >> 16;
+
+    // slot state
+    Vec3 pos = mk3(0, 0, 0), rayDir = mk3(0, 0, 0), normal = mk3(0, 0, 0), beta = mk3(1, 1, 1), result = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
+    Surface props{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+    uint32_t material = 0, sflags = 0, lightSet = 0;
+    Vec3 envL = mk3(0, 0, 0), envI = mk3(0, 0, 0); // ENV: this bounce's sampled light, when the slot samples one
+    bool envSampled = false;
+
+    bool needBounce = false, needEnd = false, needCamera = false;
+    bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
+    uint32_t reverseBits = 0;
+
+    if (phase == PH_START) {
+        if (pixel == 0xffffffffu || packets == 0u) {
+            phase = PH_DONE;
+            if (pixel != 0xffffffffu && slot == 0) { // samples < 8: the reference still writes 0/samples
+                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
+                px[0] = px[1] = px[2] = A.p.exposure * (0.0f / (float)samples);
+                ws.px++;
+                ws.rays += samples;
+            }
+        } else {
+            needCamera = true;
+            if (slot == 0) ws.rays += samples; // path_tracer.cpp:62
+        }
+    } else if (phase == PH_WAIT_PRIMARY) {
+        // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
+        float4 ha = nt_load4(&A.hitA[gs]);
+        uint2 hb = A.hitB[gs];
+        float4 s2 = nt_load4(&A.S2[gs]); // the primary ray's direction
+        Vec3 pdir = mk3(s2.x, s2.y, s2.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+        DevHit h{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
+        bool isHit = h.t != -1.0f;
+        Surf5 sv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+        Vec3 snormal = mk3(0, 0, 0), spos = mk3(0, 0, 0);
+        if (isHit) {
+            Surface s;
+            get_surface<COUNT>(sc, h, s, tr);
+            sv = Surf5{s.normal, s.uv, s.mat, s.prim};
+            snormal = sample_bump<COUNT>(sc, s.mat, s, tr);
+            spos = add3(scale3(h.t, pdir), porg);
+        }
+        uint32_t hm = group_ballot(isHit, gbase);
+        alive = __popc(hm);
+        uint32_t src = gbase + ((slot < alive) ? nth_set(hm, slot) : slot);
+        props.normal = sh3(sv.normal, src);
+        props.uv = Vec2{shf(sv.uv.x, src), shf(sv.uv.y, src)};
+        props.mat = shu(sv.mat, src);
+        props.prim = shu(sv.prim, src);
+        material = props.mat;
+        normal = sh3(snormal, src);
+        pos = sh3(spos, src);
+        rayDir = sh3(pdir, src);
+        beta = mk3(1.0f, 1.0f, 1.0f);
+        result = mk3(0.0f, 0.0f, 0.0f);
+        lightSet = 0;
+        depth = 0;
+        alive0 = alive;
+        if (alive != 0u && depth < maxDepth) needBounce = true;
+        else needEnd = true;
+    } else if (phase == PH_WAIT_BOUNCE) {
+        uint32_t pmat = 0;
+        if (slot < alive) { // dead slots carry nothing
+            float4 s0 = nt_load4(&A.S0[gs]), s1 = nt_load4(&A.S1[gs]), s2 = nt_load4(&A.S2[gs]), s3 = nt_load4(&A.S3[gs]);
+            pos = mk3(s0.x, s0.y, s0.z);
+            pmat = asu(s0.w);
+            normal = mk3(s1.x, s1.y, s1.z);
+            sflags = asu(s1.w);
+            ndir = mk3(s2.x, s2.y, s2.z);
+            beta = mk3(s3.x, s3.y, s3.z);
+            float4 s4 = nt_load4(&A.S4[gs]);
+            result = mk3(s4.x, s4.y, s4.z);
+        }
+        props.mat = pmat;
+        lightSet = (sflags & SLOT_LIGHT_SET) ? 1u : 0u;
+        // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
+        if (sflags & SLOT_HAS_SHADOW) {
+            if (A.occl[gs] == 0u) {
+                Vec3 lightDir = mk3(0, 0, 0), lightInt = mk3(0, 0, 0);
+                if (lightSet) {
+                    if (ENV) {
+                        float4 l5 = nt_load4(&A.S5[gs]), l6 = nt_load4(&A.S6[gs]);
+                        lightDir = mk3(l5.x, l5.y, l5.z);
+                        lightInt = mk3(l6.x, l6.y, l6.z);
+                    } else {
+                        lightDir = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
+                        lightInt = mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]);
+                    }
+                }
+                Vec3 lr = div3s(scale3(std_max(dot3(lightDir, normal), 0.0f), lightInt), kPi);
+                result = add3(result, mul3(beta, lr));
+            }
+        }
+        // ---- scatter hits, ordered compaction into slot ci (path_tracer.cpp:281-293)
+        bool hitNext = false;
+        Surface ns{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+        Vec3 npos = mk3(0, 0, 0);
+        if (sflags & SLOT_SURVIVE) {
+            float4 ha = nt_load4(&A.hitA[gs]);
+            uint2 hb = A.hitB[gs];
+            DevHit nh{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
+            if (nh.t != -1.0f) {
+                hitNext = true;
+                get_surface<COUNT>(sc, nh, ns, tr);
+                npos = add3(scale3(nh.t, ndir), pos);
+            }
+        }
+        uint32_t nm = group_ballot(hitNext, gbase);
+        uint32_t nAlive = __popc(nm);
+        if (nAlive == 0u) {
+            needEnd = true; // path_tracer.cpp:295
+        } else {
+            uint32_t ci = __popc(nm & lowerMask);
+            uint32_t smat = 0;
+            Vec3 snorm = mk3(0, 0, 0);
+            Surf5 nv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
+            if (hitNext) {
+                // materials[ci] = props[i].material reads the slot's PREVIOUS surface unless ci == i (:286-288)
+                smat = (ci == slot) ? ns.mat : props.mat;
+                snorm = sample_bump<COUNT>(sc, smat, ns, tr);
+                nv = Surf5{ns.normal, ns.uv, ns.mat, ns.prim};
+            }
+            // beta[ci] = beta[i]/(1-q) is only written under Russian roulette (:263); q is a function of beta
+            Vec3 betaNew = beta;
+            if (depth > rrDepth) {
+                float q = std_max(0.05f, 1.0f - length3(beta));
+                betaNew = div3s(beta, 1.0f - q);
+            }
+            uint32_t src2 = gbase + ((slot < nAlive) ? nth_set(nm, slot) : slot);
+            props.normal = sh3(nv.normal, src2);
+            props.uv = Vec2{shf(nv.uv.x, src2), shf(nv.uv.y, src2)};
+            props.mat = shu(nv.mat, src2);
+            props.prim = shu(nv.prim, src2);
+            material = shu(smat, src2);
+            normal = sh3(snorm, src2);
+            pos = sh3(npos, src2);
+            rayDir = sh3(ndir, src2);
+            Vec3 bmoved = sh3(betaNew, src2);
+            if (depth > rrDepth && slot < nAlive) beta = bmoved;
+            alive = nAlive;
+            depth++;
+            if (depth < maxDepth) needBounce = true;
+            else needEnd = true;
+        }
+    }
+
+    if (needBounce) {
+        // ---- one bounce (path_tracer.cpp:131-190 and the Russian roulette of :258-265)
+        const bool active = slot < alive;
+        uint32_t rtype = 2u;
+        if (active) {
+            const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)material;
+            float4 m0 = mp[0], m1 = mp[1];
+            rtype = asu(m0.w);
+            if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
+        }
+        const bool draws = active && (rtype == 0u || rtype == 1u);
+        uint32_t dm = group_ballot(draws, gbase);
+        uint32_t pre = 2u * __popc(dm & lowerMask), tot = 2u * __popc(dm);
+        if (ENV) { // a diffuse slot draws two more for InfiniteAreaLight::sample (:164-167), after its r2, r1
+            uint32_t em = group_ballot(active && rtype == 0u, gbase);
+            pre += 2u * __popc(em & lowerMask);
+            tot += 2u * __popc(em);
+        }
+        uint32_t s = rng, r2b = 0, r1b = 0, uxb = 0, uyb = 0;
+        for (uint32_t j = 0; j < tot; j++) {
+            s = xorshift32(s);
+            if (j == pre) r2b = s;
+            if (j == pre + 1u) r1b = s;
+            if (ENV && j == pre + 2u) uxb = s;
+            if (ENV && j == pre + 3u) uyb = s;
+        }
+        rng = s;
+        Vec3 nextDir = mk3(0, 0, 0);
+        bool wantLight = false;
+        if (draws) {
+            Vec3 dd = diffuse_dir(normal, rng_to_float(r2b), rng_to_float(r1b));
+            if (rtype == 0u) {
+                nextDir = dd;
+                beta = mul3(beta, sample_diffuse<COUNT>(sc, material, props.uv, tr)); // :162
+                if (ENV) { // :164-167
+                    env_sample<COUNT>(sc, rng_to_float(uxb), rng_to_float(uyb), envL, envI, tr);
+                    envSampled = true;
+                    lightSet = 1u;
+                    wantLight = true;
+                } else if (sc.hasLight) { // :168-172
+                    lightSet = 1u;
+                    wantLight = true;
+                }
+            } else {
+                Vec3 reflectDir = sub3(rayDir, scale3(dot3(normal, rayDir), scale3(2.0f, normal))); // :186
+                nextDir = add3(scale3(0.9f, reflectDir), scale3(0.1f, dd));
+            }
+        }
+        const bool directLighting = group_ballot(wantLight, gbase) != 0u;
+        sflags = 0;
+        if (directLighting && active) { // :196-252: every alive path gets an occlusion ray
+            emitShadow = true; // the occlusion traversal builds org = pos + kFar*L, dir = -L from the slot's state
+            shadowPacket = (alive & 0xfu) > 2u; // :198
+            sflags |= SLOT_HAS_SHADOW;
+            ws.rays++;
+            ws.occl++;
+        }
+        bool survive = active;
+        if (depth > rrDepth) { // one draw per alive slot, in slot order
+            uint32_t s2 = rng, ub = 0;
+            for (uint32_t j = 0; j < alive; j++) {
+                s2 = xorshift32(s2);
+                if (j == slot) ub = s2;
+            }
+            rng = s2;
+            if (active) {
+                float q = std_max(0.05f, 1.0f - length3(beta));
+                if (rng_to_float(ub) < q) survive = false;
+            }
+        }
+        if (survive) {
+            ndir = normalize3(nextDir); // :267
+            emitScatter = true;
+            sflags |= SLOT_SURVIVE;
+            ws.rays++;
+        }
+        phase = PH_WAIT_BOUNCE;
+    }
+
+    if (needEnd) {
+        // ---- sum of result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71).  Slots whose path ended in an earlier
+        // round left their result in memory.
+        if (slot >= aliveAtEntry && slot < alive0 && phase == PH_WAIT_BOUNCE) {
+            float4 s4 = nt_load4(&A.S4[gs]);
+            result = mk3(s4.x, s4.y, s4.z);
+        }
+        Vec3 res = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t l = 0; l < 8; l++) res = add3(res, sh3(result, gbase + l));
+        color = add3(color, res);
+        pk++;
+        if (pk < packets) {
+            needCamera = true;
+        } else {
+            Vec3 c = scale3(A.p.exposure, div3s(color, (float)samples)); // path_tracer.cpp:28, image.cpp:45
+            if (slot == 0) {
+                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
+                px[0] = c.x;
+                px[1] = c.y;
+                px[2] = c.z;
+                ws.px++;
+            }
+            phase = PH_DONE;
+        }
+    }
+
+    if (needCamera) {
+        DevRay pr;
+        Vec3 avgDir;
+        camera_packet(cam, rng, x, y, slot, gbase, pr, avgDir);
+        reverseBits = (avgDir.x < 0.0f ? 1u : 0u) | (avgDir.y < 0.0f ? 2u : 0u) | (avgDir.z < 0.0f ? 4u : 0u);
+        ndir = pr.dir;
+        emitPrimary = true;
+        phase = PH_WAIT_PRIMARY;
+    }
+
+    // ---- the rays of the next round go to the block's queues: lane rank by wave ballot + popcount behind the caller's tails
+    const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
+    const uint32_t owner = poolLocal * 8u + slot; // slot index inside the block's pool (< PRT_POOL_SLOTS)
+    uint32_t emitted = 0;
+#pragma unroll
+    for (int q = 0; q < Q_COUNT; q++) {
+        const unsigned long long mask = __ballot(want[q]);
+        if (mask == 0ull) continue; // wave-uniform
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (want[q]) {
+            const uint32_t idx = (tails[q] + rank) & (PRT_POOL_SLOTS - 1u);
+            const uint32_t bits = owner | (q == Q_PRIMARY ? (reverseBits << 26) : 0u) | (q >= Q_OCC_PACKET ? (lightSet << 29) : 0u);
+            __builtin_nontemporal_store(bits, &blockQ[q * PRT_POOL_SLOTS + idx]);
+        }
+        tails[q] += (uint32_t)__popcll(mask);
+        emitted += (uint32_t)__popc(((uint32_t)(mask >> gbase)) & 0xffu); // of this lane's group
+    }
+
+    // ---- store state
+    if (inRange && ((info >> 20) & 0xfu) != PH_DONE) {
+        if (phase == PH_WAIT_BOUNCE && slot < alive) {
+            nt_store4(&A.S0[gs], make_float4(pos.x, pos.y, pos.z, asf(props.mat)));
+            nt_store4(&A.S1[gs], make_float4(normal.x, normal.y, normal.z, asf(sflags | (lightSet ? SLOT_LIGHT_SET : 0u))));
+            nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
+            nt_store4(&A.S3[gs], make_float4(beta.x, beta.y, beta.z, 0.0f));
+            if (ENV && envSampled) {
+                nt_store4(&A.S5[gs], make_float4(envL.x, envL.y, envL.z, 0.0f));
+                nt_store4(&A.S6[gs], make_float4(envI.x, envI.y, envI.z, 0.0f));
+            }
+        }
+        // a slot's result is stored while the slot is alive and once more in the round its path ends
+        if (phase == PH_WAIT_BOUNCE && slot < (aliveAtEntry > alive ? aliveAtEntry : alive))
+            nt_store4(&A.S4[gs], make_float4(result.x, result.y, result.z, 0.0f));
+        if (phase == PH_WAIT_PRIMARY) nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
+        if (slot == 0) {
+            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20) | ((alive0 & 0xfu) << 24);
+            A.gRng[g] = rng;
+            A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
+        }
+    }
+    return phase == PH_DONE ? PEND_DONE : emitted;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- trace
+// Persistent lanes over one of the block's ray queues.  A lane takes a new ray the moment its own finishes; the wave leaves
+// when the queue is empty and its last ray is done.  A finished ray's result is stored to the owner slot and the owner
+// group's pending word is decremented one loop turn later -- by then the step phase in between has waited for younger
+// loads, so the store has completed (vector memory operations of a wave retire in order) and the release fence is free.
+template <int MODE, bool COUNT, class STK>
+__device__ __noinline__ void trace_queue(const FrameArgs& A, BlockState& B, const uint32_t* blockQ, uint32_t slotBase, const STK& st, Traffic& tr,
+                                            uint32_t& overflow)
+{
+    const DevScene& sc = A.sc;
+    const uint32_t lane = threadIdx.x & 63u;
+    const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
+    const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
+    const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
+    Tracer T;
+    T.ref = PRT_REF_NONE;
+    T.sp = 0;
+    T.m = 0;
+    bool active = false;
+    uint32_t owner = 0;      // pool slot (inside the block) of the lane's ray
+    uint32_t sig = PRT_NONE; // pool group whose pending word this lane still has to decrement
+    for (;;) {
+        // ---- 1. finished rays of the previous turn: their stores are complete -> tell the group
+        if (__any(sig != PRT_NONE)) {
+            wg_release();
+            if (sig != PRT_NONE) {
+                if (atomicSub(&B.pending[sig], 1u) == 1u) atomicAdd(&B.ready, 1u);
+                sig = PRT_NONE;
+            }
+        }
+        // ---- 2. refill
+        const unsigned long long need = __ballot(!active);
+        if (need) {
+            const uint32_t k = (uint32_t)__popcll(need);
+            uint32_t base = 0, got = 0;
+            if (lane == 0 && !(lds_ld(&B.ready) >= PRT_DRAIN_READY && lds_ld(&B.lock) == 0u)) {
+                for (int tries = 0; tries < 16; tries++) {
+                    const uint32_t t = lds_ld_acq(&B.qTail[MODE]), h = lds_ld(&B.qHead[MODE]);
+                    const int32_t avail = (int32_t)(t - h);
+                    if (avail <= 0) break;
+                    const uint32_t take = k < (uint32_t)avail ? k : (uint32_t)avail;
+                    if (atomicCAS(&B.qHead[MODE], h, h + take) == h) {
+                        base = h;
+                        got = take;
+                        break;
+                    }
+                }
+            }
+            base = bcast0(base);
+            got = bcast0(got);
+            if (!active) {
+                const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (r < got) {
+                    const uint32_t bits = __builtin_nontemporal_load(&blockQ[MODE * PRT_POOL_SLOTS + ((base + r) & (PRT_POOL_SLOTS - 1u))]);
+                    owner = bits & 0x3ffffffu;
+                    const uint32_t gs = slotBase + owner;
+                    Vec3 org, dir;
+                    float maxT;
+                    uint32_t rev = (bits >> 26) & 7u;
+                    if (MODE == PRT_MODE_PACKET) {
+                        float4 s2 = nt_load4(&A.S2[gs]);
+                        org = camPos;
+                        dir = mk3(s2.x, s2.y, s2.z);
+                        maxT = 100000.0f; // camera.cpp:64
+                    } else if (MODE == PRT_MODE_SINGLE) {
+                        float4 s0 = nt_load4(&A.S0[gs]), s2 = nt_load4(&A.S2[gs]);
+                        org = mk3(s0.x, s0.y, s0.z);
+                        dir = mk3(s2.x, s2.y, s2.z);
+                        maxT = kFar; // path_tracer.cpp:270
+                    } else {
+                        float4 s0 = nt_load4(&A.S0[gs]);
+                        Vec3 L = mk3(0.0f, 0.0f, 0.0f);
+                        if ((bits >> 29) & 1u) {
+                            if (sc.hasEnv) {
+                                float4 l5 = nt_load4(&A.S5[gs]);
+                                L = mk3(l5.x, l5.y, l5.z);
+                            } else {
+                                L = sceneLight;
+                            }
+                        }
+                        org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
+                        dir = mk3(-L.x, -L.y, -L.z);
+                        maxT = kFar - 0.0008f; // :209, 236
+                    }
+                    tracer_begin<MODE>(T, org, dir, maxT, rev);
+                    // NaN rays: see trace_loop (answered at once in the timed build, walked in the counting build)
+                    if (!COUNT && !(org.x == org.x && org.y == org.y && org.z == org.z && dir.x == dir.x && dir.y == dir.y && dir.z == dir.z))
+                        T.m = sc.bvhCount - 1u;
+                    active = true;
+                }
+            }
+        }
+        if (!__any(active)) break;
+        // ---- 3. rays that have left their last BVH
+        if (active && T.ref == PRT_REF_NONE) {
+            if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
+                const uint32_t gs = slotBase + owner;
+                if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
+                    if (T.hit.t == T.maxT) T.hit.t = -1.0f; // setMissForMaxT, scene.cpp:62
+                    nt_store4(&A.hitA[gs], make_float4(T.hit.t, T.hit.i, T.hit.j, T.hit.k));
+                    A.hitB[gs] = make_uint2(T.hit.primId, T.hit.meshId);
+                } else {
+                    A.occl[gs] = T.occ ? 1u : 0u;
+                }
+                sig = owner >> 3;
+                active = false;
+            }
+        }
+        // ---- 4. step
+        trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- roles
+// Shade role (the caller holds the lock): give empty rows new work, then sweep the pending words and run the ready groups.
+template <bool COUNT, bool ENV>
+__device__ __noinline__ bool shade_role(const FrameArgs& A, BlockState& B, uint32_t* blockQ, uint32_t poolBase, WaveStats& ws, Traffic& tr)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    bool did = false;
+    // ---- rows whose groups are all done take the next 64 work items
+    for (uint32_t row = 0; row < A.rowsPerBlock; row++) {
+        if (lds_ld(&B.chunkLive[row]) != 0u || lds_ld(&B.exhausted) != 0u) continue;
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&A.ctrl[0], 1u);
+        c = bcast0(c);
+        if (c >= A.totalChunks) {
+            if (lane == 0) lds_st(&B.exhausted, 1u);
+            break;
+        }
+        const uint32_t w = c * PRT_CHUNK + lane;
+        const bool valid = w < A.totalWork;
+        const uint32_t P = poolBase + row * PRT_CHUNK + lane;
+        if (valid) {
+            const uint32_t pixel = work_item_pixel(A, w);
+            A.gPixel[P] = pixel;
+            A.gRng[P] = pixel != 0xffffffffu ? pixel_seed(pixel & 0xffffu, pixel >> 16, A.cam.width, A.p.seed) : 0u;
+            A.gInfo[P] = (uint32_t)PH_START << 20;
+            A.gColor[P] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        lds_st(&B.pending[row * PRT_CHUNK + lane], valid ? 0u : PEND_DONE);
+        const uint32_t n = (uint32_t)__popcll(__ballot(valid));
+        if (lane == 0) {
+            lds_st(&B.chunkLive[row], n);
+            atomicAdd(&B.live, n);
+            atomicAdd(&B.ready, n);
+        }
+        did = true;
+    }
+    wg_release(); // the group headers above are read back below (other lanes of this wave) and by later shade rounds
+    // ---- sweep
+    uint32_t tails[Q_COUNT];
+#pragma unroll
+    for (int q = 0; q < Q_COUNT; q++) tails[q] = lds_ld(&B.qTail[q]);
+    for (uint32_t row = 0; row < PRT_POOL_CHUNKS; row++) {
+        if (lds_ld(&B.chunkLive[row]) == 0u) continue;
+        for (uint32_t guard = 0; guard < 4096u; guard++) {
+            const uint32_t v = lds_ld_acq(&B.pending[row * PRT_CHUNK + lane]);
+            unsigned long long m = __ballot(v == 0u);
+            if (m == 0ull) break;
+            // up to 8 ready groups: lanes 8j..8j+7 take the j-th set bit
+            uint32_t gi = PRT_NONE, taken = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                if (m == 0ull) break;
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                if ((lane >> 3) == j) gi = b;
+                taken++;
+            }
+            const uint32_t local = gi != PRT_NONE ? row * PRT_CHUNK + gi : 0u;
+            const uint32_t np = shade_pass<COUNT, ENV>(A, gi != PRT_NONE ? poolBase + local : PRT_NONE, local, tails, blockQ, ws, tr);
+            // publish: state and queue entries first, then the pending words, then the tails
+            wg_release();
+            const bool head = gi != PRT_NONE && (lane & 7u) == 0u;
+            if (head) lds_st(&B.pending[local], np);
+            const uint32_t nDone = (uint32_t)__popcll(__ballot(head && np == PEND_DONE));
+            const uint32_t nAgain = (uint32_t)__popcll(__ballot(head && np == 0u));
+            if (lane == 0) {
+                if (nDone) {
+                    atomicSub(&B.chunkLive[row], nDone);
+                    atomicSub(&B.live, nDone);
+                }
+                atomicSub(&B.ready, taken - nAgain);
+            }
+#pragma unroll
+            for (int q = 0; q < Q_COUNT; q++)
+                if (lane == 0) lds_st_rel(&B.qTail[q], tails[q]);
+            did = true;
+        }
+    }
+    return did;
+}
+
+template <bool COUNT, bool ENV>
+__global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const FrameArgs* __restrict__ Ap)
+{
+    const FrameArgs& A = *Ap; // the arguments live in device memory: fields are fetched by scalar loads where they are used
+    // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
+    __shared__ uint32_t ldsStack[PRT_STACK_LDS * PRT_BLOCK];
+    __shared__ BlockState B;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t i = tid; i < PRT_POOL_GROUPS; i += PRT_BLOCK) B.pending[i] = PEND_DONE;
+    if (tid < PRT_POOL_CHUNKS) B.chunkLive[tid] = 0;
+    if (tid < Q_COUNT) {
+        B.qTail[tid] = 0;
+        B.qHead[tid] = 0;
+    }
+    if (tid == 0) {
+        B.lock = 0;
+        B.ready = 0;
+        B.live = 0;
+        B.exhausted = 0;
+        B.abort = 0;
+    }
+    __syncthreads();
+    const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS, slotBase = poolBase * 8u;
+    uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
+    uint32_t* spillCol = A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid);
+    const StackT<PRT_STACK_LDS> stRef{(lds_u32*)&ldsStack[tid], (lds_f32*)&ldsStack[tid], spillCol, A.spillStride};
+    const StackT<PRT_STACK_LDS_PACKET> stPair{(lds_u32*)&ldsStack[tid], (lds_f32*)&ldsStack[PRT_STACK_LDS_PACKET * PRT_BLOCK + tid], spillCol, A.spillStride};
+    WaveStats ws{0, 0, 0};
+    Traffic tr{0, 0, 0, 0};
+    uint32_t overflow = 0, idle = 0;
+    for (;;) {
+        bool did = false;
+        // ---- decision point: this wave holds no rays
+        uint32_t backlog[Q_COUNT], total = 0, best = 0;
+#pragma unroll
+        for (int q = 0; q < Q_COUNT; q++) {
+            const int32_t d = (int32_t)(lds_ld_acq(&B.qTail[q]) - lds_ld(&B.qHead[q]));
+            backlog[q] = d > 0 ? (uint32_t)d : 0u;
+            total += backlog[q];
+            if (backlog[q] > backlog[best]) best = (uint32_t)q;
+        }
+        const uint32_t ready = lds_ld(&B.ready), live = lds_ld(&B.live), exhausted = lds_ld(&B.exhausted);
+        const bool roomForRows = exhausted == 0u && live + PRT_CHUNK <= A.rowsPerBlock * PRT_CHUNK;
+        if (ready >= PRT_SHADE_MIN || (ready > 0u && total < 64u) || (roomForRows && total < 64u) || (roomForRows && ready + live == 0u)) {
+            uint32_t got = 0;
+            if (lane == 0) got = atomicCAS(&B.lock, 0u, 1u) == 0u ? 1u : 0u;
+            if (bcast0(got)) {
+                wg_acquire();
+                did = shade_role<COUNT, ENV>(A, B, blockQ, poolBase, ws, tr);
+                if (lane == 0) lds_st_rel(&B.lock, 0u);
+            }
+        }
+        if (!did && total > 0u) {
+            best = bcast0(best);
+            if (best == Q_PRIMARY) trace_queue<PRT_MODE_PACKET, COUNT>(A, B, blockQ, slotBase, stPair, tr, overflow);
+            else if (best == Q_SCATTER) trace_queue<PRT_MODE_SINGLE, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
+            else if (best == Q_OCC_PACKET) trace_queue<PRT_MODE_OCC_PACKET, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
+            else trace_queue<PRT_MODE_OCC_SINGLE, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
+            did = true;
+        }
+        if (did) {
+            idle = 0;
+            continue;
+        }
+        if (lds_ld(&B.exhausted) != 0u && lds_ld(&B.live) == 0u) break; // nothing left and nothing can arrive
+        if (lds_ld(&B.abort) != 0u) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle > (1u << 24)) { // watchdog: a scheduling bug must end as an error code, never as a hung GPU
+            if (lane == 0) {
+                lds_st(&B.abort, 1u);
+                atomicExch(&A.ctrl[1], 1u);
+            }
+            break;
+        }
+    }
+    // ---- statistics: wave sums, one atomic per wave and counter on one of PRT_STAT_SHARDS copies
+    {
+        unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+        const uint32_t r = wave_sum(ws.rays), o = wave_sum(ws.occl), px = wave_sum(ws.px);
+        if (lane == 0) {
+            if (r) atomicAdd(&C[0], (unsigned long long)r);
+            if (o) atomicAdd(&C[1], (unsigned long long)o);
+            if (px) atomicAdd(&C[6], (unsigned long long)px);
+        }
+        if (COUNT) {
+            unsigned long long b = tr.nBox, t = tr.nTri, h = tr.nHit, p = tr.nTap;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                b += (unsigned long long)__shfl_xor((long long)b, o2, 64);
+                t += (unsigned long long)__shfl_xor((long long)t, o2, 64);
+                h += (unsigned long long)__shfl_xor((long long)h, o2, 64);
+                p += (unsigned long long)__shfl_xor((long long)p, o2, 64);
+            }
+            if (lane == 0) {
+                if (b) atomicAdd(&C[2], b);
+                if (t) atomicAdd(&C[3], t);
+                if (h) atomicAdd(&C[4], h);
+                if (p) atomicAdd(&C[5], p);
+            }
+        }
+        if (overflow) atomicAdd(&C[7], 1ull);
+    }
+}

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -196,6 +197,7 @@ int prt_hip_comm_init(prt_hip_ctx* c, const void* id, int rank, int nranks)
     memcpy(&u, id, sizeof(u));
     void* comm = nullptr;
     RCCL_TRY(*R, R->CommInitRank(&comm, nranks, u, rank));
+    if (!comm) return prt_fail(PRT_HIP_ECOMM, "ncclCommInitRank succeeded but returned no communicator");
     c->comm = comm;
     c->commOwned = true;
     c->commRank = rank;
@@ -240,7 +242,11 @@ int prt_hip_comm_destroy(prt_hip_ctx* c)
 int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
 {
     if (!c) return prt_fail(PRT_HIP_EINVAL, "ctx is NULL");
-    if (!c->comm) return prt_fail(PRT_HIP_ESTATE, "no communicator: call prt_hip_comm_init or prt_hip_comm_adopt first");
+    if (!c->comm) {
+        char where[64];
+        snprintf(where, sizeof(where), " (ctx %p, size %d)", (void*)c, c->commSize);
+        return prt_fail(PRT_HIP_ESTATE, std::string("no communicator: call prt_hip_comm_init or prt_hip_comm_adopt first") + where);
+    }
     if (root < 0 || root >= c->commSize) return prt_fail(PRT_HIP_EINVAL, "root outside the communicator");
     if (!c->haveCamera || c->lastTile == 0) return prt_fail(PRT_HIP_ESTATE, "nothing rendered yet");
     if (c->lastNranks != (uint32_t)c->commSize || c->lastRank != (uint32_t)c->commRank)

@@ -84,6 +84,10 @@ struct prt_hip_ctx {
     float* stageBuf = nullptr;  // root: the other ranks' tiles as received
     size_t stageFloats = 0;
     int blocksPerCU = 0;
+    int frameBlocksPerCU = 0;  // resident blocks per CU of the frame kernel
+    bool frameLaunched = false;
+    void* frameArgs = nullptr;  // device copies of the frame kernel's argument block (ring)
+    uint32_t frameArgSlot = 0;
     bool timed = false;
 };
 

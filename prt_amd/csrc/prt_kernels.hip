@@ -763,6 +763,8 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     if (overflow) atomicAdd(&C[7], 1ull);
 }
 
+#include "prt_frame.h"
+
 // ============================================================================ G-buffer visualiser
 // GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): per pixel ONE jittered single ray (Camera::GenerateJitteredRay,
 // camera.cpp:12-33: two generateMinus1to1 draws from the pixel's generator), the single-ray nearest traversal, then the
@@ -1119,6 +1121,7 @@ void prt_hip_destroy(prt_hip_ctx* c)
     if (c->counters) (void)hipFree(c->counters);
     if (c->spill) (void)hipFree(c->spill);
     if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+    if (c->frameArgs) (void)hipFree(c->frameArgs);
     prt_gather_release(c);
     for (int k = 0; k < PRT_TIMING_RING; k++) {
         if (c->evT0[k]) (void)hipEventDestroy(c->evT0[k]);
@@ -1427,6 +1430,7 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env
     }
     if (need > c->wfBytes) {
         if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+    if (c->frameArgs) (void)hipFree(c->frameArgs);
     prt_gather_release(c);
         c->wfBuffer = nullptr;
         c->wfBytes = 0;
@@ -1452,6 +1456,94 @@ static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env
         A[k].hitB = (uint2*)take(slots * sizeof(uint2));
         A[k].occl = (uint32_t*)take(slots * sizeof(uint32_t));
         for (int q = 0; q < Q_COUNT; q++) A[k].qE[q] = (uint32_t*)take(entries(slots) * sizeof(uint32_t));
+    }
+    return PRT_HIP_OK;
+}
+
+// ---- frame kernel (prt_frame.h): resident blocks, pool state carved out of one allocation, one launch per render
+static int frame_blocks(prt_hip_ctx* c)
+{
+    if (c->frameBlocksPerCU == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, frame_kernel<false, false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
+        // No block waits for another one, so a block the hardware admits later than the query says only starts later.
+        c->frameBlocksPerCU = std::min(nb, 8);
+        if (const char* e = getenv("PRT_FRAME_BPC")) c->frameBlocksPerCU = std::max(1, std::min(8, atoi(e)));
+    }
+    return c->computeUnits * c->frameBlocksPerCU;
+}
+
+static int frame_layout(prt_hip_ctx* c, uint32_t blocks, bool env, FrameArgs& A)
+{
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t groups = (size_t)blocks * PRT_POOL_GROUPS, slots = groups * 8;
+    size_t need = 3 * al(groups * sizeof(uint32_t)) + al(groups * sizeof(float4));
+    need += (env ? 7 : 5) * al(slots * sizeof(float4));
+    need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t));
+    need += al((size_t)blocks * Q_COUNT * PRT_POOL_SLOTS * sizeof(uint32_t));
+    if (need > c->wfBytes) {
+        if (c->wfBuffer) (void)hipFree(c->wfBuffer);
+        c->wfBuffer = nullptr;
+        c->wfBytes = 0;
+        HIP_TRY(hipMalloc(&c->wfBuffer, need));
+        c->wfBytes = need;
+    }
+    char* p = (char*)c->wfBuffer;
+    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return r; };
+    A.gRng = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gInfo = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gPixel = (uint32_t*)take(groups * sizeof(uint32_t));
+    A.gColor = (float4*)take(groups * sizeof(float4));
+    A.S0 = (float4*)take(slots * sizeof(float4));
+    A.S1 = (float4*)take(slots * sizeof(float4));
+    A.S2 = (float4*)take(slots * sizeof(float4));
+    A.S3 = (float4*)take(slots * sizeof(float4));
+    A.S4 = (float4*)take(slots * sizeof(float4));
+    A.S5 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
+    A.S6 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
+    A.hitA = (float4*)take(slots * sizeof(float4));
+    A.hitB = (uint2*)take(slots * sizeof(uint2));
+    A.occl = (uint32_t*)take(slots * sizeof(uint32_t));
+    A.qE = (uint32_t*)take((size_t)blocks * Q_COUNT * PRT_POOL_SLOTS * sizeof(uint32_t));
+    return PRT_HIP_OK;
+}
+
+static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalWork, hipStream_t s)
+{
+    const prt_render_params* p = &W0.p;
+    FrameArgs A{};
+    A.sc = W0.sc; A.cam = W0.cam; A.p = W0.p;
+    A.x0 = W0.x0; A.y0 = W0.y0; A.x1 = W0.x1; A.y1 = W0.y1;
+    A.tilesXImage = W0.tilesXImage;
+    A.rtx0 = W0.rtx0; A.rty0 = W0.rty0; A.rtnx = W0.rtnx; A.rtny = W0.rtny;
+    A.fullWidth = W0.fullWidth; A.firstOwned = W0.firstOwned;
+    A.totalWork = (uint32_t)totalWork;
+    A.totalChunks = (uint32_t)((totalWork + PRT_CHUNK - 1) / PRT_CHUNK);
+    A.rgb = W0.rgb;
+    A.counters = c->counters;
+    A.ctrl = c->work;
+    const uint32_t resident = (uint32_t)frame_blocks(c);
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(resident, A.totalChunks));
+    // a block holds at most rowsPerBlock rows at a time: all of a small launch's rows are in flight at once, spread evenly
+    A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (A.totalChunks + blocks - 1) / blocks));
+    int rc = ensure_launch_resources(c, std::max<uint32_t>(resident, (uint32_t)persistent_blocks(c)));
+    if (rc) return rc;
+    A.spill = c->spill;
+    A.spillStride = c->spillThreads;
+    if ((rc = frame_layout(c, resident, c->sc.hasEnv != 0, A))) return rc;
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), s));
+    if (A.totalChunks == 0) return PRT_HIP_OK;
+    // the argument block travels through a small device buffer (one per launch in flight: a ring of PRT_TIMING_RING)
+    if (!c->frameArgs) HIP_TRY(hipMalloc(&c->frameArgs, PRT_TIMING_RING * sizeof(FrameArgs)));
+    FrameArgs* dA = (FrameArgs*)c->frameArgs + (c->frameArgSlot++ % PRT_TIMING_RING);
+    HIP_TRY(hipMemcpyAsync(dA, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, s));
+    const bool env = c->sc.hasEnv != 0;
+    if (p->countTraffic) {
+        if (env) hipLaunchKernelGGL((frame_kernel<true, true>), dim3(blocks), dim3(PRT_BLOCK), 0, s, dA);
+        else hipLaunchKernelGGL((frame_kernel<true, false>), dim3(blocks), dim3(PRT_BLOCK), 0, s, dA);
+    } else {
+        if (env) hipLaunchKernelGGL((frame_kernel<false, true>), dim3(blocks), dim3(PRT_BLOCK), 0, s, dA);
+        else hipLaunchKernelGGL((frame_kernel<false, false>), dim3(blocks), dim3(PRT_BLOCK), 0, s, dA);
     }
     return PRT_HIP_OK;
 }
@@ -1527,6 +1619,33 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     A.rgb = d_rgb;
     A.qWork = c->work;
     A.counters = c->counters;
+    static const bool useWavefrontPipeline = getenv("PRT_SCHED") && !strcmp(getenv("PRT_SCHED"), "wave"); // A/B during development
+    if (!useWavefrontPipeline) {
+        if (p->tileSize * p->tileSize > (1u << 20)) return fail(PRT_HIP_EINVAL, "tile too large");
+        HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
+        if (c->ringUsed == PRT_TIMING_RING) fold_timing(c);
+        if (!c->evT0[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT0[c->ringUsed]));
+        if (!c->evT1[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT1[c->ringUsed]));
+        hipEvent_t e0 = c->evT0[c->ringUsed], e1 = c->evT1[c->ringUsed];
+        c->ringUsed++;
+        HIP_TRY(hipEventRecord(e0, s));
+        int frc = render_frame_kernel(c, A, totalWork, s);
+        if (frc) return frc;
+        hipError_t fle = hipGetLastError();
+        if (fle != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("frame_kernel launch: ") + hipGetErrorString(fle));
+        HIP_TRY(hipEventRecord(e1, s));
+        c->lastRank = p->rank;
+        c->lastNranks = p->nranks;
+        c->lastTile = p->tileSize;
+        c->lastTarget = d_rgb;
+        if (caller) {
+            HIP_TRY(hipEventRecord(c->evOut, s));
+            HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
+        }
+        c->timed = true;
+        c->frameLaunched = true;
+        return PRT_HIP_OK;
+    }
     const uint32_t traceBlocks = (uint32_t)persistent_blocks(c);
     int rc = ensure_launch_resources(c, traceBlocks);
     if (rc) return rc;
@@ -1704,6 +1823,11 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
         fprintf(stderr, "\n");
     }
 #endif
+    if (c->frameLaunched) {
+        uint32_t ctrl[2] = {0, 0};
+        HIP_TRY(hipMemcpy(ctrl, c->work, sizeof(ctrl), hipMemcpyDeviceToHost));
+        if (ctrl[1]) return fail(PRT_HIP_ELAUNCH, "frame kernel: scheduler watchdog fired (a workgroup waited for work that never came)");
+    }
     st->raysTraced = h[0];
     st->occludedTraced = h[1];
     st->nBox = h[2];
