@@ -104,6 +104,44 @@ __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b 
 __device__ __forceinline__ float asf(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 
+// Scene and state arrays live in global memory (hipMalloc).  Where a pointer VALUE reaches the code through memory (an
+// argument block, a struct passed by reference) the compiler can no longer see that and emits flat loads, which take the
+// slower path through the address-space check; these helpers state the address space at the access.
+#define PRT_AS1 __attribute__((address_space(1)))
+typedef float prt_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t prt_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t prt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 gld4(const float4* p)
+{
+    prt_f4 v = *(const PRT_AS1 prt_f4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 gld4u(const uint4* p)
+{
+    prt_u4 v = *(const PRT_AS1 prt_u4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gld2u(const uint2* p)
+{
+    prt_u2 v = *(const PRT_AS1 prt_u2*)p;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t gld(const uint32_t* p) { return *(const PRT_AS1 uint32_t*)p; }
+__device__ __forceinline__ int32_t gld(const int32_t* p) { return *(const PRT_AS1 int32_t*)p; }
+__device__ __forceinline__ float gld(const float* p) { return *(const PRT_AS1 float*)p; }
+__device__ __forceinline__ uint32_t gld(const uint8_t* p) { return (uint32_t) * (const PRT_AS1 uint8_t*)p; }
+__device__ __forceinline__ void gst(uint32_t* p, uint32_t v) { *(PRT_AS1 uint32_t*)p = v; }
+__device__ __forceinline__ void gst4(float4* p, float4 v)
+{
+    prt_f4 w = {v.x, v.y, v.z, v.w};
+    *(PRT_AS1 prt_f4*)p = w;
+}
+__device__ __forceinline__ void gst2u(uint2* p, uint2 v)
+{
+    prt_u2 w = {v.x, v.y};
+    *(PRT_AS1 prt_u2*)p = w;
+}
+
 struct DevRay {
     Vec3 org, dir, inv;
     bool swapXZ, swapYZ;
@@ -313,7 +351,7 @@ __device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t com
 template <bool COUNT>
 __device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint32_t tex, Vec2 uv, bool soa, Traffic& tr)
 {
-    uint4 d = sc.texDesc[tex];
+    uint4 d = gld4u(&sc.texDesc[tex]);
     const uint8_t* p = sc.texels + d.x;
     float k[4];
     int32_t idx[4];
@@ -321,7 +359,7 @@ __device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint32_t tex,
     if (COUNT) tr.nTap++;
     float alpha = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) alpha = alpha + k[i] * (float)p[idx[i] + 3];
+    for (int i = 0; i < 4; i++) alpha = alpha + k[i] * (float)gld(p + idx[i] + 3);
     return alpha > 127.0f;
 }
 
@@ -337,7 +375,7 @@ __device__ __forceinline__ Vec3 tex_sample3(const DevScene& sc, uint4 d, Vec2 uv
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint8_t* q = p + idx[i];
-        c = add3(c, scale3(k[i], mk3((float)q[0], (float)q[1], (float)q[2])));
+        c = add3(c, scale3(k[i], mk3((float)gld(q), (float)gld(q + 1), (float)gld(q + 2))));
     }
     return scale3(1.0f / 255.0f, c);
 }
@@ -352,7 +390,7 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
     if (COUNT) tr.nTap++;
     float c = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) c = c + k[i] * (float)p[idx[i]];
+    for (int i = 0; i < 4; i++) c = c + k[i] * (float)gld(p + idx[i]);
     return (1.0f / 255.0f) * c;
 }
 
@@ -378,12 +416,12 @@ struct StackT {
     __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
         if (e < NLDS) ldsRef[e * PRT_BLOCK] = ref;
-        else spill[(size_t)(2 * (e - NLDS)) * spillStride] = ref;
+        else gst(&spill[(size_t)(2 * (e - NLDS)) * spillStride], ref);
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
         uint32_t v = ldsRef[(e & (NLDS - 1)) * PRT_BLOCK];
-        if (e >= NLDS) v = spill[(size_t)(2 * (e - NLDS)) * spillStride];
+        if (e >= NLDS) v = gld(&spill[(size_t)(2 * (e - NLDS)) * spillStride]);
         return v;
     }
     __device__ __forceinline__ void putT(int e, uint32_t ref, float t) const
@@ -392,14 +430,14 @@ struct StackT {
             ldsRef[e * PRT_BLOCK] = ref;
             ldsT[e * PRT_BLOCK] = t;
         } else {
-            spill[(size_t)(2 * (e - NLDS)) * spillStride] = ref;
-            spill[(size_t)(2 * (e - NLDS) + 1) * spillStride] = asu(t);
+            gst(&spill[(size_t)(2 * (e - NLDS)) * spillStride], ref);
+            gst(&spill[(size_t)(2 * (e - NLDS) + 1) * spillStride], asu(t));
         }
     }
     __device__ __forceinline__ float getT(int e) const
     {
         float v = ldsT[(e & (NLDS - 1)) * PRT_BLOCK];
-        if (e >= NLDS) v = asf(spill[(size_t)(2 * (e - NLDS) + 1) * spillStride]);
+        if (e >= NLDS) v = asf(gld(&spill[(size_t)(2 * (e - NLDS) + 1) * spillStride]));
         return v;
     }
 };
@@ -417,10 +455,10 @@ __device__ __forceinline__ void load_wide(const DevScene& sc, uint32_t idx, Wide
 {
     const float4* p = sc.wnodes + 4 * (size_t)idx;
     float4 w3;
-    w.w0 = p[0];
-    w.w1 = p[1];
-    w.w2 = p[2];
-    w3 = p[3];
+    w.w0 = gld4(p);
+    w.w1 = gld4(p + 1);
+    w.w2 = gld4(p + 2);
+    w3 = gld4(p + 3);
     w.ref0 = asu(w3.x);
     w.ref1 = asu(w3.y);
     w.axis = asu(w3.z);
@@ -438,14 +476,14 @@ template <bool OCCLUDE, bool PACKET, bool COUNT>
 __device__ __forceinline__ bool tri_candidate(const DevScene& sc, const float4* tp, uint32_t meshId, const DevRay& r, float limit, DevHit& hit,
                                               Traffic& tr)
 {
-    float4 a = tp[0], b = tp[1], c = tp[2];
+    float4 a = gld4(tp), b = gld4(tp + 1), c = gld4(tp + 2);
     float bi, bj, bk;
     float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
     if (!(t >= 0.0001f && t < limit)) return false;
     uint32_t alphaRef = asu(b.w);
     if (alphaRef) {
         const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
-        float4 u0 = ap[0], u1 = ap[1];
+        float4 u0 = gld4(ap), u1 = gld4(ap + 1);
         // i*uv0 + j*uv1 + k*uv2 (bvh.cpp:336, 407)
         Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y};
         if (!tex_test_alpha<COUNT>(sc, asu(u1.z), uv, PACKET, tr)) return false;
@@ -771,6 +809,9 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
     const uint32_t waveId = blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t staticEnd = totalWaves * chunk;
     uint32_t rangeNext = waveId * chunk, rangeEnd = rangeNext + chunk;
+#ifdef PRT_PROFILE
+    unsigned long long pTurns = 0, pLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         unsigned long long need = __ballot(!active && !exhausted);
         if (need) {
@@ -810,6 +851,10 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
             }
         }
         if (!__any(active)) break;
+#ifdef PRT_PROFILE
+        pTurns++;
+        pLanes += (unsigned long long)__popcll(__ballot(active));
+#endif
         if (active && T.ref == PRT_REF_NONE) {
             if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
                 if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
@@ -823,6 +868,11 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
         }
         trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
+#ifdef PRT_PROFILE
+    tr.nBox = pTurns; // diagnostic build: the traffic counters carry the loop statistics out (profile builds never count traffic)
+    tr.nTri = pLanes;
+    tr.nTap = (uint32_t)((__builtin_amdgcn_s_memtime() - pT0) >> 10);
+#endif
 }
 
 // ---------------------------------------------------------------------------- surface + material
@@ -840,7 +890,7 @@ __device__ __forceinline__ void get_surface(const DevScene& sc, const DevHit& h,
     if (COUNT) tr.nHit++;
     uint32_t gp = sc.primBase[h.meshId] + h.primId;
     const float4* sp = sc.shade + 4 * (size_t)gp;
-    float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+    float4 s0 = gld4(sp), s1 = gld4(sp + 1), s2 = gld4(sp + 2), s3 = gld4(sp + 3);
     if (sc.hasNormals[h.meshId]) {
         Vec3 n = add3(add3(scale3(h.i, mk3(s0.x, s0.y, s0.z)), scale3(h.j, mk3(s1.x, s1.y, s1.z))), scale3(h.k, mk3(s2.x, s2.y, s2.z)));
         s.normal = normalize3(n);
@@ -864,10 +914,10 @@ __device__ __forceinline__ int32_t cdf_find(const float* cdf, int32_t n, int32_t
     int32_t lo = 1, hi = n;
     while (lo < hi) {
         int32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] > u) hi = mid;
+        if (gld(cdf + mid) > u) hi = mid;
         else lo = mid + 1;
     }
-    if (lo == 1 && lo < n && cdf[0] > u) lo = first;
+    if (lo == 1 && lo < n && gld(cdf) > u) lo = first;
     return lo;
 }
 
@@ -878,15 +928,15 @@ __device__ __forceinline__ void env_sample(const DevScene& sc, float ux, float u
     float pdfV = 1.0f, yf = 0.0f, pdfH = 1.0f, xf = 0.0f;
     const int32_t y = cdf_find(sc.envV, H, sc.envFirstY, uy);
     if (y < H) {
-        float prev = sc.envV[y - 1];
-        pdfV = sc.envV[y] - prev;
+        float prev = gld(sc.envV + (y - 1));
+        pdfV = gld(sc.envV + y) - prev;
         yf = (float)y + (uy - prev) / pdfV - 1.0f;
         // the row of the horizontal table is the CDF index y, not the texel row y-1 (:109)
         const float* row = sc.envHor + (size_t)y * (size_t)W;
-        const int32_t x = cdf_find(row, W, sc.envFirstX[y], ux);
+        const int32_t x = cdf_find(row, W, gld(sc.envFirstX + y), ux);
         if (x < W) {
-            float prevx = row[x - 1];
-            pdfH = row[x] - prevx;
+            float prevx = gld(row + (x - 1));
+            pdfH = gld(row + x) - prevx;
             xf = (float)x + (ux - prevx) / pdfH - 1.0f;
         }
     }
@@ -899,7 +949,7 @@ __device__ __forceinline__ void env_sample(const DevScene& sc, float ux, float u
     Vec3 c = mk3(0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        float4 t = sc.envTexels[idx[i]];
+        float4 t = gld4(sc.envTexels + idx[i]);
         c = add3(c, scale3(k[i], mk3(t.x, t.y, t.z)));
     }
     c = div3s(div3s(c, pdfH * pdfV), (float)(W * H)); // :118
@@ -918,7 +968,7 @@ __device__ __forceinline__ Vec3 sample_diffuse(const DevScene& sc, uint32_t mat,
 {
     // the material record carries the descriptors of its two maps: material and descriptor arrive in one round trip
     const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)mat;
-    float4 m0 = mp[0], m2 = mp[2], m3 = mp[3];
+    float4 m0 = gld4(mp), m2 = gld4(mp + 2), m3 = gld4(mp + 3);
     Vec3 color = mk3(m0.x, m0.y, m0.z);
     int32_t tex = (int32_t)asu(m2.x);
     if (tex >= 0) {
@@ -934,11 +984,11 @@ __device__ __forceinline__ Vec3 sample_bump(const DevScene& sc, uint32_t mat, co
 {
     Vec3 normal = s.normal;
     const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)mat;
-    float4 m2 = mp[2], m4 = mp[4];
+    float4 m2 = gld4(mp + 2), m4 = gld4(mp + 4);
     int32_t tex = (int32_t)asu(m2.y);
     if (tex >= 0) {
         const float4* bp = sc.bump + 3 * (size_t)s.prim;
-        float4 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        float4 b0 = gld4(bp), b1 = gld4(bp + 1), b2 = gld4(bp + 2);
         Vec3 dp01 = mk3(b0.x, b0.y, b0.z), dp02 = mk3(b1.x, b1.y, b1.z);
         Vec2 duv01 = Vec2{b0.w, b1.w}, duv02 = Vec2{b2.x, b2.y};
         const uint4 d = make_uint4(asu(m4.x), asu(m4.y), asu(m4.z), asu(m4.w));

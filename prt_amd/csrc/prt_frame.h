@@ -32,8 +32,17 @@
 #ifndef PRT_SHADE_MIN
 #define PRT_SHADE_MIN 16u // ready groups that make a wave at a decision point take the shade role
 #endif
+#ifndef PRT_CLAIM
+#define PRT_CLAIM 128u // queue entries a wave reserves at a time
+#endif
 #ifndef PRT_DRAIN_READY
 #define PRT_DRAIN_READY 192u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
+#endif
+#ifndef PRT_ROLE_INLINE
+#define PRT_ROLE_INLINE __noinline__
+#endif
+#ifndef PRT_WATCHDOG_SPINS
+#define PRT_WATCHDOG_SPINS (1u << 22) // idle turns (about 0.3 us each) after which a wave gives up: ~1 s
 #endif
 #define PRT_CHUNK 64u
 #define PRT_POOL_GROUPS (PRT_POOL_CHUNKS * PRT_CHUNK)
@@ -76,7 +85,9 @@ struct FrameArgs {
     uint32_t spillStride;
 };
 
-struct BlockState { // LDS
+struct BlockState { // LDS, one per workgroup
+    // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
+    uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
     uint32_t pending[PRT_POOL_GROUPS];
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
     uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
@@ -85,16 +96,37 @@ struct BlockState { // LDS
     uint32_t live;      // groups in the pool that are not done
     uint32_t exhausted; // the global cursor has no more rows
     uint32_t abort;
+    uint32_t exited;    // waves that have left the role loop: the last one writes the block's statistics out
+    uint32_t overflow;  // a traversal needed more than 64 stack entries
+    uint32_t rays, occl, px;                        // stats.h:10-16
+    unsigned long long nBox, nTri, nHit, nTap;      // counting build only
 };
+typedef __attribute__((address_space(3))) BlockState* BlockLds;
+
+// The block's LDS: one object, reached from the kernel and from the role functions alike.
+__device__ __forceinline__ BlockLds block_lds()
+{
+    __shared__ BlockState blockState;
+    return (BlockLds)&blockState;
+}
 
 struct WaveStats {
     uint32_t rays, occl, px;
 };
 
-__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t lds_ld_acq(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st_rel(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// LDS words are reached through address-space-3 pointers (ds_* instructions with constant offsets); a generic reference to
+// the block's LDS would turn every access into a flat operation.
+typedef __attribute__((address_space(3))) uint32_t lds_w;
+__device__ __forceinline__ uint32_t lds_ld(const lds_w* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_ld_acq(const lds_w* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(lds_w* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st_rel(lds_w* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_add(lds_w* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_sub(lds_w* p, uint32_t v) { return __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ bool lds_cas(lds_w* p, uint32_t expect, uint32_t v)
+{
+    return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // every global store of this wave has completed and is visible to the other waves of the workgroup (same CU, same L1)
 __device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -121,6 +153,19 @@ __device__ __forceinline__ uint32_t work_item_pixel(const FrameArgs& A, uint32_t
     return ok ? (x | (y << 16)) : 0xffffffffu;
 }
 
+// The roles are real (not inlined) functions, so that each gets the registers of a kernel of its own size.  They reach the
+// launch's arguments through the kernel-argument segment, whose address the kernel hands them as a plain integer (a callable
+// function has no kernel-argument pointer of its own): rebuilt from readfirstlane halves it is a uniform pointer into constant
+// memory, so fields arrive by scalar loads where they are used, and the data pointers in them are dereferenced as global
+// addresses (gld / gst / nt_*) with a scalar base -- the code a kernel with by-value arguments gets.
+typedef const __attribute__((address_space(4))) FrameArgs* FrameKernargs;
+__device__ __forceinline__ uint64_t frame_kernarg_bits() { return (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ const FrameArgs& frame_args(uint64_t bits)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
+    return *(const FrameArgs*)(FrameKernargs)(((uint64_t)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- shade
 // One shade round of up to 8 pixel groups (lanes 8j..8j+7 = the 8 path slots of group j).  P = the group's index into the
 // pool state, PRT_NONE for lanes without a group.  Consumes the hits of the group's last rays, runs the bounce of
@@ -128,8 +173,8 @@ __device__ __forceinline__ uint32_t work_item_pixel(const FrameArgs& A, uint32_t
 // who holds the shade lock and publishes them).  Returns, in every lane of the group, the group's new pending word: the
 // number of rays emitted, or PEND_DONE when the pixel has been written.
 template <bool COUNT, bool ENV>
-__device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, uint32_t poolLocal, uint32_t (&tails)[Q_COUNT], uint32_t* blockQ,
-                                               WaveStats& ws, Traffic& tr)
+__device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, uint32_t P, uint32_t poolLocal, uint32_t* blockQ, WaveStats& ws,
+                                               Traffic& tr)
 {
     const uint32_t lane = threadIdx.x & 63u, slot = lane & 7u, gbase = lane & ~7u;
     const bool inRange = P != PRT_NONE;
@@ -142,16 +187,16 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
     const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
     const uint32_t lowerMask = (1u << slot) - 1u;
 
-    uint32_t info = inRange ? A.gInfo[g] : ((uint32_t)PH_DONE << 20);
+    uint32_t info = inRange ? gld(&A.gInfo[g]) : ((uint32_t)PH_DONE << 20);
     uint32_t phase = (info >> 20) & 0xfu, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
     uint32_t alive0 = (info >> 24) & 0xfu; // slots that have held a path in this packet: the others' result is still 0
     const uint32_t aliveAtEntry = (phase == PH_WAIT_BOUNCE) ? alive : 0u;
     uint32_t rng = 0, pixel = 0xffffffffu;
     Vec3 color = mk3(0, 0, 0);
     if (inRange) {
-        rng = A.gRng[g];
-        pixel = A.gPixel[g];
-        float4 c = A.gColor[g];
+        rng = gld(&A.gRng[g]);
+        pixel = gld(&A.gPixel[g]);
+        float4 c = gld4(&A.gColor[g]);
         color = mk3(c.x, c.y, c.z);
     }
     const uint32_t x = pixel & 0xffffu, y = pixel >> 16;
@@ -171,8 +216,11 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         if (pixel == 0xffffffffu || packets == 0u) {
             phase = PH_DONE;
             if (pixel != 0xffffffffu && slot == 0) { // samples < 8: the reference still writes 0/samples
-                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
-                px[0] = px[1] = px[2] = A.p.exposure * (0.0f / (float)samples);
+                uint32_t* px = (uint32_t*)(A.rgb + ((size_t)x + (size_t)y * cam.width) * 3);
+                const uint32_t zero = asu(A.p.exposure * (0.0f / (float)samples));
+                gst(px, zero);
+                gst(px + 1, zero);
+                gst(px + 2, zero);
                 ws.px++;
                 ws.rays += samples;
             }
@@ -183,7 +231,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
     } else if (phase == PH_WAIT_PRIMARY) {
         // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
         float4 ha = nt_load4(&A.hitA[gs]);
-        uint2 hb = A.hitB[gs];
+        uint2 hb = gld2u(&A.hitB[gs]);
         float4 s2 = nt_load4(&A.S2[gs]); // the primary ray's direction
         Vec3 pdir = mk3(s2.x, s2.y, s2.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
         DevHit h{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
@@ -232,7 +280,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         lightSet = (sflags & SLOT_LIGHT_SET) ? 1u : 0u;
         // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
         if (sflags & SLOT_HAS_SHADOW) {
-            if (A.occl[gs] == 0u) {
+            if (gld(&A.occl[gs]) == 0u) {
                 Vec3 lightDir = mk3(0, 0, 0), lightInt = mk3(0, 0, 0);
                 if (lightSet) {
                     if (ENV) {
@@ -254,7 +302,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         Vec3 npos = mk3(0, 0, 0);
         if (sflags & SLOT_SURVIVE) {
             float4 ha = nt_load4(&A.hitA[gs]);
-            uint2 hb = A.hitB[gs];
+            uint2 hb = gld2u(&A.hitB[gs]);
             DevHit nh{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
             if (nh.t != -1.0f) {
                 hitNext = true;
@@ -307,7 +355,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         uint32_t rtype = 2u;
         if (active) {
             const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)material;
-            float4 m0 = mp[0], m1 = mp[1];
+            float4 m0 = gld4(mp), m1 = gld4(mp + 1);
             rtype = asu(m0.w);
             if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
         }
@@ -397,10 +445,10 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         } else {
             Vec3 c = scale3(A.p.exposure, div3s(color, (float)samples)); // path_tracer.cpp:28, image.cpp:45
             if (slot == 0) {
-                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
-                px[0] = c.x;
-                px[1] = c.y;
-                px[2] = c.z;
+                uint32_t* px = (uint32_t*)(A.rgb + ((size_t)x + (size_t)y * cam.width) * 3);
+                gst(px, asu(c.x));
+                gst(px + 1, asu(c.y));
+                gst(px + 2, asu(c.z));
                 ws.px++;
             }
             phase = PH_DONE;
@@ -417,21 +465,24 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
         phase = PH_WAIT_PRIMARY;
     }
 
-    // ---- the rays of the next round go to the block's queues: lane rank by wave ballot + popcount behind the caller's tails
+    // ---- the rays of the next round go to the block's queues: lane rank by wave ballot + popcount behind the queue's tail
+    // (only the wave that holds the shade lock appends, so the tails are plain LDS words for it)
     const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
     const uint32_t owner = poolLocal * 8u + slot; // slot index inside the block's pool (< PRT_POOL_SLOTS)
-    uint32_t emitted = 0;
+    uint32_t emitted = 0, newTail[Q_COUNT];
 #pragma unroll
     for (int q = 0; q < Q_COUNT; q++) {
         const unsigned long long mask = __ballot(want[q]);
+        newTail[q] = 0;
         if (mask == 0ull) continue; // wave-uniform
+        const uint32_t tail = bcast0(lds_ld(&B->qTail[q]));
         const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (want[q]) {
-            const uint32_t idx = (tails[q] + rank) & (PRT_POOL_SLOTS - 1u);
+            const uint32_t idx = (tail + rank) & (PRT_POOL_SLOTS - 1u);
             const uint32_t bits = owner | (q == Q_PRIMARY ? (reverseBits << 26) : 0u) | (q >= Q_OCC_PACKET ? (lightSet << 29) : 0u);
-            __builtin_nontemporal_store(bits, &blockQ[q * PRT_POOL_SLOTS + idx]);
+            nt_store(&blockQ[q * PRT_POOL_SLOTS + idx], bits);
         }
-        tails[q] += (uint32_t)__popcll(mask);
+        newTail[q] = tail + (uint32_t)__popcll(mask);
         emitted += (uint32_t)__popc(((uint32_t)(mask >> gbase)) & 0xffu); // of this lane's group
     }
 
@@ -452,12 +503,39 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
             nt_store4(&A.S4[gs], make_float4(result.x, result.y, result.z, 0.0f));
         if (phase == PH_WAIT_PRIMARY) nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
         if (slot == 0) {
-            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20) | ((alive0 & 0xfu) << 24);
-            A.gRng[g] = rng;
-            A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
+            gst(&A.gInfo[g], (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20) | ((alive0 & 0xfu) << 24));
+            gst(&A.gRng[g], rng);
+            gst4(&A.gColor[g], make_float4(color.x, color.y, color.z, 0.0f));
         }
     }
-    return phase == PH_DONE ? PEND_DONE : emitted;
+    // ---- publish: state and queue entries have to be complete before the pending words, and those before the tails
+    const uint32_t np = phase == PH_DONE ? PEND_DONE : emitted;
+    wg_release();
+    if (inRange && slot == 0u) lds_st(&B->pending[poolLocal], np);
+#pragma unroll
+    for (int q = 0; q < Q_COUNT; q++)
+        if (newTail[q] != 0u && lane == 0u) lds_st_rel(&B->qTail[q], newTail[q]);
+    return np;
+}
+
+// Counting build: a role call's event counts go to the block's 64-bit sums.
+__device__ __forceinline__ void block_count_traffic(BlockLds B, const Traffic& tr)
+{
+    unsigned long long b = tr.nBox, t = tr.nTri, h = tr.nHit, p = tr.nTap;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        b += (unsigned long long)__shfl_xor((long long)b, o, 64);
+        t += (unsigned long long)__shfl_xor((long long)t, o, 64);
+        h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+        p += (unsigned long long)__shfl_xor((long long)p, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        typedef __attribute__((address_space(3))) unsigned long long lds_q;
+        if (b) __hip_atomic_fetch_add((lds_q*)&B->nBox, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t) __hip_atomic_fetch_add((lds_q*)&B->nTri, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (h) __hip_atomic_fetch_add((lds_q*)&B->nHit, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p) __hip_atomic_fetch_add((lds_q*)&B->nTap, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- trace
@@ -465,15 +543,23 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, uint32_t P, u
 // when the queue is empty and its last ray is done.  A finished ray's result is stored to the owner slot and the owner
 // group's pending word is decremented one loop turn later -- by then the step phase in between has waited for younger
 // loads, so the store has completed (vector memory operations of a wave retire in order) and the release fence is free.
-template <int MODE, bool COUNT, class STK>
-__device__ __noinline__ void trace_queue(const FrameArgs& A, BlockState& B, const uint32_t* blockQ, uint32_t slotBase, const STK& st, Traffic& tr,
-                                            uint32_t& overflow)
+template <int MODE, bool COUNT>
+__device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
 {
+    constexpr int NLDS = (MODE == PRT_MODE_PACKET) ? PRT_STACK_LDS_PACKET : PRT_STACK_LDS;
+    const FrameArgs& A = frame_args(kargs);
+    const BlockLds B = block_lds();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t slotBase = blockIdx.x * PRT_POOL_SLOTS;
+    const uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
+    const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid),
+                          A.spillStride};
     const DevScene& sc = A.sc;
-    const uint32_t lane = threadIdx.x & 63u;
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
     const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
+    Traffic tr{0, 0, 0, 0};
+    uint32_t overflow = 0;
     Tracer T;
     T.ref = PRT_REF_NONE;
     T.sp = 0;
@@ -481,78 +567,130 @@ __device__ __noinline__ void trace_queue(const FrameArgs& A, BlockState& B, cons
     bool active = false;
     uint32_t owner = 0;      // pool slot (inside the block) of the lane's ray
     uint32_t sig = PRT_NONE; // pool group whose pending word this lane still has to decrement
+    uint32_t held[PRT_CLAIM / 64u];     // queue entries the wave has claimed and not yet handed to a lane
+    uint32_t heldNext = 0, heldEnd = 0; // which of them are left (wave-uniform)
+#pragma unroll
+    for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) held[j] = 0;
+#ifdef PRT_PROFILE
+    unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pT0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         // ---- 1. finished rays of the previous turn: their stores are complete -> tell the group
         if (__any(sig != PRT_NONE)) {
             wg_release();
             if (sig != PRT_NONE) {
-                if (atomicSub(&B.pending[sig], 1u) == 1u) atomicAdd(&B.ready, 1u);
+                if (lds_sub(&B->pending[sig], 1u) == 1u) lds_add(&B->ready, 1u);
                 sig = PRT_NONE;
             }
         }
-        // ---- 2. refill
+        // ---- 2. refill.  The wave takes PRT_CLAIM entries of the queue at a time and hands them to its lanes as they come
+        // free: consecutive entries are rays of neighbouring pixels at the same bounce, and lanes that walk the same part of
+        // the tree step together.  The entries are READ when they are claimed and wait in registers (held[]): the ring's
+        // capacity argument -- at most one ray per slot and mode is out -- only holds for entries consumed in order.
         const unsigned long long need = __ballot(!active);
         if (need) {
             const uint32_t k = (uint32_t)__popcll(need);
-            uint32_t base = 0, got = 0;
-            if (lane == 0 && !(lds_ld(&B.ready) >= PRT_DRAIN_READY && lds_ld(&B.lock) == 0u)) {
-                for (int tries = 0; tries < 16; tries++) {
-                    const uint32_t t = lds_ld_acq(&B.qTail[MODE]), h = lds_ld(&B.qHead[MODE]);
-                    const int32_t avail = (int32_t)(t - h);
-                    if (avail <= 0) break;
-                    const uint32_t take = k < (uint32_t)avail ? k : (uint32_t)avail;
-                    if (atomicCAS(&B.qHead[MODE], h, h + take) == h) {
-                        base = h;
-                        got = take;
-                        break;
-                    }
+            const uint32_t avail = heldEnd - heldNext; // wave-uniform
+            const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            uint32_t bits = 0;
+            bool gotRay = false;
+            if (avail != 0u) { // hand out what the wave holds: entry heldNext + r sits in lane (e & 63) of held[e >> 6]
+                const uint32_t e = heldNext + r;
+#pragma unroll
+                for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) {
+                    const uint32_t v = shu(held[j], e & 63u);
+                    if ((e >> 6) == j) bits = v;
                 }
+                gotRay = r < avail;
             }
-            base = bcast0(base);
-            got = bcast0(got);
-            if (!active) {
-                const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (r < got) {
-                    const uint32_t bits = __builtin_nontemporal_load(&blockQ[MODE * PRT_POOL_SLOTS + ((base + r) & (PRT_POOL_SLOTS - 1u))]);
-                    owner = bits & 0x3ffffffu;
-                    const uint32_t gs = slotBase + owner;
-                    Vec3 org, dir;
-                    float maxT;
-                    uint32_t rev = (bits >> 26) & 7u;
-                    if (MODE == PRT_MODE_PACKET) {
-                        float4 s2 = nt_load4(&A.S2[gs]);
-                        org = camPos;
-                        dir = mk3(s2.x, s2.y, s2.z);
-                        maxT = 100000.0f; // camera.cpp:64
-                    } else if (MODE == PRT_MODE_SINGLE) {
-                        float4 s0 = nt_load4(&A.S0[gs]), s2 = nt_load4(&A.S2[gs]);
-                        org = mk3(s0.x, s0.y, s0.z);
-                        dir = mk3(s2.x, s2.y, s2.z);
-                        maxT = kFar; // path_tracer.cpp:270
-                    } else {
-                        float4 s0 = nt_load4(&A.S0[gs]);
-                        Vec3 L = mk3(0.0f, 0.0f, 0.0f);
-                        if ((bits >> 29) & 1u) {
-                            if (sc.hasEnv) {
-                                float4 l5 = nt_load4(&A.S5[gs]);
-                                L = mk3(l5.x, l5.y, l5.z);
-                            } else {
-                                L = sceneLight;
-                            }
+            if (avail < k) { // wave-uniform: the held entries are used up, take the next range
+                uint32_t newBase = 0, newGot = 0;
+                if (lane == 0 && !(lds_ld(&B->ready) >= PRT_DRAIN_READY && lds_ld(&B->lock) == 0u)) {
+                    for (int tries = 0; tries < 16; tries++) {
+                        const uint32_t t = lds_ld_acq(&B->qTail[MODE]), h = lds_ld(&B->qHead[MODE]);
+                        const int32_t queued = (int32_t)(t - h);
+                        if (queued <= 0) break;
+                        const uint32_t take = PRT_CLAIM < (uint32_t)queued ? PRT_CLAIM : (uint32_t)queued;
+                        if (lds_cas(&B->qHead[MODE], h, h + take)) {
+                            newBase = h;
+                            newGot = take;
+                            break;
                         }
-                        org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
-                        dir = mk3(-L.x, -L.y, -L.z);
-                        maxT = kFar - 0.0008f; // :209, 236
                     }
-                    tracer_begin<MODE>(T, org, dir, maxT, rev);
-                    // NaN rays: see trace_loop (answered at once in the timed build, walked in the counting build)
-                    if (!COUNT && !(org.x == org.x && org.y == org.y && org.z == org.z && dir.x == dir.x && dir.y == dir.y && dir.z == dir.z))
-                        T.m = sc.bvhCount - 1u;
-                    active = true;
                 }
+                newBase = bcast0(newBase);
+                newGot = bcast0(newGot);
+#pragma unroll
+                for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) {
+                    const uint32_t e = j * 64u + lane;
+                    held[j] = e < newGot ? nt_load(&blockQ[MODE * PRT_POOL_SLOTS + ((newBase + e) & (PRT_POOL_SLOTS - 1u))]) : 0u;
+                }
+                const uint32_t want = k - avail, used = want < newGot ? want : newGot;
+                {
+                    const uint32_t e = r - avail; // meaningful for the lanes that take from the new range; every lane shuffles
+                    uint32_t fresh = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) {
+                        const uint32_t v = shu(held[j], e & 63u);
+                        if ((e >> 6) == j) fresh = v;
+                    }
+                    if (r >= avail && e < newGot) {
+                        bits = fresh;
+                        gotRay = true;
+                    }
+                }
+                heldNext = used;
+                heldEnd = newGot;
+            } else {
+                heldNext += k;
+            }
+#ifdef PRT_PROFILE
+            pClaims++;
+            if (!__any(gotRay)) pEmptyClaims++;
+#endif
+            if (!active && gotRay) {
+                owner = bits & 0x3ffffffu;
+                const uint32_t gs = slotBase + owner;
+                Vec3 org, dir;
+                float maxT;
+                uint32_t rev = (bits >> 26) & 7u;
+                if (MODE == PRT_MODE_PACKET) {
+                    float4 s2 = nt_load4(&A.S2[gs]);
+                    org = camPos;
+                    dir = mk3(s2.x, s2.y, s2.z);
+                    maxT = 100000.0f; // camera.cpp:64
+                } else if (MODE == PRT_MODE_SINGLE) {
+                    float4 s0 = nt_load4(&A.S0[gs]), s2 = nt_load4(&A.S2[gs]);
+                    org = mk3(s0.x, s0.y, s0.z);
+                    dir = mk3(s2.x, s2.y, s2.z);
+                    maxT = kFar; // path_tracer.cpp:270
+                } else {
+                    float4 s0 = nt_load4(&A.S0[gs]);
+                    Vec3 L = mk3(0.0f, 0.0f, 0.0f);
+                    if ((bits >> 29) & 1u) {
+                        if (sc.hasEnv) {
+                            float4 l5 = nt_load4(&A.S5[gs]);
+                            L = mk3(l5.x, l5.y, l5.z);
+                        } else {
+                            L = sceneLight;
+                        }
+                    }
+                    org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
+                    dir = mk3(-L.x, -L.y, -L.z);
+                    maxT = kFar - 0.0008f; // :209, 236
+                }
+                tracer_begin<MODE>(T, org, dir, maxT, rev);
+                // NaN rays: see trace_loop (answered at once in the timed build, walked in the counting build)
+                if (!COUNT && !(org.x == org.x && org.y == org.y && org.z == org.z && dir.x == dir.x && dir.y == dir.y && dir.z == dir.z))
+                    T.m = sc.bvhCount - 1u;
+                active = true;
             }
         }
         if (!__any(active)) break;
+#ifdef PRT_PROFILE
+        pTurns++;
+        pLanes += (unsigned long long)__popcll(__ballot(active));
+#endif
         // ---- 3. rays that have left their last BVH
         if (active && T.ref == PRT_REF_NONE) {
             if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
@@ -560,9 +698,9 @@ __device__ __noinline__ void trace_queue(const FrameArgs& A, BlockState& B, cons
                 if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
                     if (T.hit.t == T.maxT) T.hit.t = -1.0f; // setMissForMaxT, scene.cpp:62
                     nt_store4(&A.hitA[gs], make_float4(T.hit.t, T.hit.i, T.hit.j, T.hit.k));
-                    A.hitB[gs] = make_uint2(T.hit.primId, T.hit.meshId);
+                    gst2u(&A.hitB[gs], make_uint2(T.hit.primId, T.hit.meshId));
                 } else {
-                    A.occl[gs] = T.occ ? 1u : 0u;
+                    gst(&A.occl[gs], T.occ ? 1u : 0u);
                 }
                 sig = owner >> 3;
                 active = false;
@@ -571,23 +709,41 @@ __device__ __noinline__ void trace_queue(const FrameArgs& A, BlockState& B, cons
         // ---- 4. step
         trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
+    if (overflow) lds_st(&B->overflow, 1u);
+    if (COUNT) block_count_traffic(B, tr);
+#ifdef PRT_PROFILE
+    if (lane == 0) {
+        unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+        atomicAdd(&C[16 + MODE * 3], pTurns);
+        atomicAdd(&C[17 + MODE * 3], pLanes);
+        atomicAdd(&C[18 + MODE * 3], (__builtin_amdgcn_s_memtime() - pT0) >> 10);
+        atomicAdd(&C[28], pClaims);
+        atomicAdd(&C[29], pEmptyClaims);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------- roles
 // Shade role (the caller holds the lock): give empty rows new work, then sweep the pending words and run the ready groups.
 template <bool COUNT, bool ENV>
-__device__ __noinline__ bool shade_role(const FrameArgs& A, BlockState& B, uint32_t* blockQ, uint32_t poolBase, WaveStats& ws, Traffic& tr)
+__device__ PRT_ROLE_INLINE bool shade_role(uint64_t kargs)
 {
+    const FrameArgs& A = frame_args(kargs);
+    const BlockLds B = block_lds();
+    const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS;
+    uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     const uint32_t lane = threadIdx.x & 63u;
+    WaveStats ws{0, 0, 0};
+    Traffic tr{0, 0, 0, 0};
     bool did = false;
     // ---- rows whose groups are all done take the next 64 work items
     for (uint32_t row = 0; row < A.rowsPerBlock; row++) {
-        if (lds_ld(&B.chunkLive[row]) != 0u || lds_ld(&B.exhausted) != 0u) continue;
+        if (bcast0(lds_ld(&B->chunkLive[row])) != 0u || bcast0(lds_ld(&B->exhausted)) != 0u) continue;
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(&A.ctrl[0], 1u);
         c = bcast0(c);
         if (c >= A.totalChunks) {
-            if (lane == 0) lds_st(&B.exhausted, 1u);
+            if (lane == 0) lds_st(&B->exhausted, 1u);
             break;
         }
         const uint32_t w = c * PRT_CHUNK + lane;
@@ -595,29 +751,26 @@ __device__ __noinline__ bool shade_role(const FrameArgs& A, BlockState& B, uint3
         const uint32_t P = poolBase + row * PRT_CHUNK + lane;
         if (valid) {
             const uint32_t pixel = work_item_pixel(A, w);
-            A.gPixel[P] = pixel;
-            A.gRng[P] = pixel != 0xffffffffu ? pixel_seed(pixel & 0xffffu, pixel >> 16, A.cam.width, A.p.seed) : 0u;
-            A.gInfo[P] = (uint32_t)PH_START << 20;
-            A.gColor[P] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            gst(&A.gPixel[P], pixel);
+            gst(&A.gRng[P], pixel != 0xffffffffu ? pixel_seed(pixel & 0xffffu, pixel >> 16, A.cam.width, A.p.seed) : 0u);
+            gst(&A.gInfo[P], (uint32_t)PH_START << 20);
+            gst4(&A.gColor[P], make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         }
-        lds_st(&B.pending[row * PRT_CHUNK + lane], valid ? 0u : PEND_DONE);
+        lds_st(&B->pending[row * PRT_CHUNK + lane], valid ? 0u : PEND_DONE);
         const uint32_t n = (uint32_t)__popcll(__ballot(valid));
         if (lane == 0) {
-            lds_st(&B.chunkLive[row], n);
-            atomicAdd(&B.live, n);
-            atomicAdd(&B.ready, n);
+            lds_st(&B->chunkLive[row], n);
+            lds_add(&B->live, n);
+            lds_add(&B->ready, n);
         }
         did = true;
     }
     wg_release(); // the group headers above are read back below (other lanes of this wave) and by later shade rounds
     // ---- sweep
-    uint32_t tails[Q_COUNT];
-#pragma unroll
-    for (int q = 0; q < Q_COUNT; q++) tails[q] = lds_ld(&B.qTail[q]);
     for (uint32_t row = 0; row < PRT_POOL_CHUNKS; row++) {
-        if (lds_ld(&B.chunkLive[row]) == 0u) continue;
+        if (bcast0(lds_ld(&B->chunkLive[row])) == 0u) continue;
         for (uint32_t guard = 0; guard < 4096u; guard++) {
-            const uint32_t v = lds_ld_acq(&B.pending[row * PRT_CHUNK + lane]);
+            const uint32_t v = lds_ld_acq(&B->pending[row * PRT_CHUNK + lane]);
             unsigned long long m = __ballot(v == 0u);
             if (m == 0ull) break;
             // up to 8 ready groups: lanes 8j..8j+7 take the j-th set bit
@@ -631,129 +784,170 @@ __device__ __noinline__ bool shade_role(const FrameArgs& A, BlockState& B, uint3
                 taken++;
             }
             const uint32_t local = gi != PRT_NONE ? row * PRT_CHUNK + gi : 0u;
-            const uint32_t np = shade_pass<COUNT, ENV>(A, gi != PRT_NONE ? poolBase + local : PRT_NONE, local, tails, blockQ, ws, tr);
-            // publish: state and queue entries first, then the pending words, then the tails
-            wg_release();
+            const uint32_t np = shade_pass<COUNT, ENV>(A, B, gi != PRT_NONE ? poolBase + local : PRT_NONE, local, blockQ, ws, tr);
+            // (shade_pass has published the groups' state, their pending words and the queue tails, in that order)
             const bool head = gi != PRT_NONE && (lane & 7u) == 0u;
-            if (head) lds_st(&B.pending[local], np);
             const uint32_t nDone = (uint32_t)__popcll(__ballot(head && np == PEND_DONE));
             const uint32_t nAgain = (uint32_t)__popcll(__ballot(head && np == 0u));
             if (lane == 0) {
                 if (nDone) {
-                    atomicSub(&B.chunkLive[row], nDone);
-                    atomicSub(&B.live, nDone);
+                    lds_sub(&B->chunkLive[row], nDone);
+                    lds_sub(&B->live, nDone);
                 }
-                atomicSub(&B.ready, taken - nAgain);
+                lds_sub(&B->ready, taken - nAgain);
             }
-#pragma unroll
-            for (int q = 0; q < Q_COUNT; q++)
-                if (lane == 0) lds_st_rel(&B.qTail[q], tails[q]);
             did = true;
         }
+    }
+    // ---- this call's statistics to the block
+    {
+        const uint32_t r = wave_sum(ws.rays), o = wave_sum(ws.occl), px = wave_sum(ws.px);
+        if (lane == 0) {
+            if (r) lds_add(&B->rays, r);
+            if (o) lds_add(&B->occl, o);
+            if (px) lds_add(&B->px, px);
+        }
+        if (COUNT) block_count_traffic(B, tr);
     }
     return did;
 }
 
 template <bool COUNT, bool ENV>
-__global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const FrameArgs* __restrict__ Ap)
+__global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const FrameArgs kernargs)
 {
-    const FrameArgs& A = *Ap; // the arguments live in device memory: fields are fetched by scalar loads where they are used
-    // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
-    __shared__ uint32_t ldsStack[PRT_STACK_LDS * PRT_BLOCK];
-    __shared__ BlockState B;
+    const uint64_t kargs = frame_kernarg_bits();
+    const FrameArgs& A = frame_args(kargs);
+    const BlockLds B = block_lds();
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t i = tid; i < PRT_POOL_GROUPS; i += PRT_BLOCK) B.pending[i] = PEND_DONE;
-    if (tid < PRT_POOL_CHUNKS) B.chunkLive[tid] = 0;
+    for (uint32_t i = tid; i < PRT_POOL_GROUPS; i += PRT_BLOCK) B->pending[i] = PEND_DONE;
+    if (tid < PRT_POOL_CHUNKS) B->chunkLive[tid] = 0;
     if (tid < Q_COUNT) {
-        B.qTail[tid] = 0;
-        B.qHead[tid] = 0;
+        B->qTail[tid] = 0;
+        B->qHead[tid] = 0;
     }
     if (tid == 0) {
-        B.lock = 0;
-        B.ready = 0;
-        B.live = 0;
-        B.exhausted = 0;
-        B.abort = 0;
+        B->lock = 0;
+        B->ready = 0;
+        B->live = 0;
+        B->exhausted = 0;
+        B->abort = 0;
+        B->exited = 0;
+        B->overflow = 0;
+        B->rays = B->occl = B->px = 0;
+        B->nBox = B->nTri = B->nHit = B->nTap = 0;
     }
     __syncthreads();
-    const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS, slotBase = poolBase * 8u;
-    uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
-    uint32_t* spillCol = A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid);
-    const StackT<PRT_STACK_LDS> stRef{(lds_u32*)&ldsStack[tid], (lds_f32*)&ldsStack[tid], spillCol, A.spillStride};
-    const StackT<PRT_STACK_LDS_PACKET> stPair{(lds_u32*)&ldsStack[tid], (lds_f32*)&ldsStack[PRT_STACK_LDS_PACKET * PRT_BLOCK + tid], spillCol, A.spillStride};
-    WaveStats ws{0, 0, 0};
-    Traffic tr{0, 0, 0, 0};
-    uint32_t overflow = 0, idle = 0;
+    uint32_t idle = 0;
+#ifdef PRT_PROFILE
+    unsigned long long tShade = 0, tTrace = 0, tIdle = 0, nShade = 0, nTrace = 0, t0 = __builtin_amdgcn_s_memtime(), tStart = t0;
+#define PROF(acc, cnt)                                            \
+    do {                                                          \
+        unsigned long long t1_ = __builtin_amdgcn_s_memtime();    \
+        acc += t1_ - t0;                                          \
+        cnt;                                                      \
+        t0 = t1_;                                                 \
+    } while (0)
+#else
+#define PROF(acc, cnt)
+#endif
     for (;;) {
         bool did = false;
+        PROF(tIdle, (void)0);
         // ---- decision point: this wave holds no rays
-        uint32_t backlog[Q_COUNT], total = 0, best = 0;
+        uint32_t total = 0, best = 0, bestLen = 0;
 #pragma unroll
         for (int q = 0; q < Q_COUNT; q++) {
-            const int32_t d = (int32_t)(lds_ld_acq(&B.qTail[q]) - lds_ld(&B.qHead[q]));
-            backlog[q] = d > 0 ? (uint32_t)d : 0u;
-            total += backlog[q];
-            if (backlog[q] > backlog[best]) best = (uint32_t)q;
+            const int32_t d = (int32_t)(lds_ld_acq(&B->qTail[q]) - lds_ld(&B->qHead[q]));
+            const uint32_t len = d > 0 ? (uint32_t)d : 0u;
+            total += len;
+            if (len > bestLen) {
+                bestLen = len;
+                best = (uint32_t)q;
+            }
         }
-        const uint32_t ready = lds_ld(&B.ready), live = lds_ld(&B.live), exhausted = lds_ld(&B.exhausted);
+        const uint32_t ready = lds_ld(&B->ready), live = lds_ld(&B->live), exhausted = lds_ld(&B->exhausted);
         const bool roomForRows = exhausted == 0u && live + PRT_CHUNK <= A.rowsPerBlock * PRT_CHUNK;
         if (ready >= PRT_SHADE_MIN || (ready > 0u && total < 64u) || (roomForRows && total < 64u) || (roomForRows && ready + live == 0u)) {
             uint32_t got = 0;
-            if (lane == 0) got = atomicCAS(&B.lock, 0u, 1u) == 0u ? 1u : 0u;
+            if (lane == 0) got = lds_cas(&B->lock, 0u, 1u) ? 1u : 0u;
             if (bcast0(got)) {
                 wg_acquire();
-                did = shade_role<COUNT, ENV>(A, B, blockQ, poolBase, ws, tr);
-                if (lane == 0) lds_st_rel(&B.lock, 0u);
+                did = shade_role<COUNT, ENV>(kargs);
+                if (lane == 0) lds_st_rel(&B->lock, 0u);
+                PROF(tShade, nShade++);
             }
         }
         if (!did && total > 0u) {
             best = bcast0(best);
-            if (best == Q_PRIMARY) trace_queue<PRT_MODE_PACKET, COUNT>(A, B, blockQ, slotBase, stPair, tr, overflow);
-            else if (best == Q_SCATTER) trace_queue<PRT_MODE_SINGLE, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
-            else if (best == Q_OCC_PACKET) trace_queue<PRT_MODE_OCC_PACKET, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
-            else trace_queue<PRT_MODE_OCC_SINGLE, COUNT>(A, B, blockQ, slotBase, stRef, tr, overflow);
+            if (best == Q_PRIMARY) trace_queue<PRT_MODE_PACKET, COUNT>(kargs);
+            else if (best == Q_SCATTER) trace_queue<PRT_MODE_SINGLE, COUNT>(kargs);
+            else if (best == Q_OCC_PACKET) trace_queue<PRT_MODE_OCC_PACKET, COUNT>(kargs);
+            else trace_queue<PRT_MODE_OCC_SINGLE, COUNT>(kargs);
             did = true;
+            PROF(tTrace, nTrace++);
         }
         if (did) {
             idle = 0;
             continue;
         }
-        if (lds_ld(&B.exhausted) != 0u && lds_ld(&B.live) == 0u) break; // nothing left and nothing can arrive
-        if (lds_ld(&B.abort) != 0u) break;
+        if (lds_ld(&B->exhausted) != 0u && lds_ld(&B->live) == 0u) break; // nothing left and nothing can arrive
+        if (lds_ld(&B->abort) != 0u) break;
         __builtin_amdgcn_s_sleep(8);
-        if (++idle > (1u << 24)) { // watchdog: a scheduling bug must end as an error code, never as a hung GPU
+        if (++idle > PRT_WATCHDOG_SPINS) { // watchdog: a scheduling bug must end as an error code, never as a hung GPU
+            // what the block looked like, for the host's error message (first 8 waves that give up)
+            uint32_t stuck = 0, sum = 0;
+            for (uint32_t i = lane; i < PRT_POOL_GROUPS; i += 64u) {
+                const uint32_t v = lds_ld(&B->pending[i]);
+                if (v != PEND_DONE && v != 0u) {
+                    stuck++;
+                    sum += v;
+                }
+            }
+            stuck = wave_sum(stuck);
+            sum = wave_sum(sum);
             if (lane == 0) {
-                lds_st(&B.abort, 1u);
+                lds_st(&B->abort, 1u);
                 atomicExch(&A.ctrl[1], 1u);
+                const uint32_t k = atomicAdd(&A.ctrl[2], 1u);
+                if (k < 8u) {
+                    uint32_t* D = A.ctrl + 8 + 16 * k;
+                    D[0] = blockIdx.x; D[1] = tid >> 6; D[2] = lds_ld(&B->ready); D[3] = lds_ld(&B->live); D[4] = lds_ld(&B->exhausted);
+                    D[5] = lds_ld(&B->lock); D[6] = stuck; D[7] = sum;
+                    for (int q = 0; q < Q_COUNT; q++) {
+                        D[8 + q] = lds_ld(&B->qTail[q]);
+                        D[12 + q] = lds_ld(&B->qHead[q]);
+                    }
+                }
             }
             break;
         }
     }
-    // ---- statistics: wave sums, one atomic per wave and counter on one of PRT_STAT_SHARDS copies
-    {
-        unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
-        const uint32_t r = wave_sum(ws.rays), o = wave_sum(ws.occl), px = wave_sum(ws.px);
-        if (lane == 0) {
-            if (r) atomicAdd(&C[0], (unsigned long long)r);
-            if (o) atomicAdd(&C[1], (unsigned long long)o);
-            if (px) atomicAdd(&C[6], (unsigned long long)px);
-        }
+    // ---- statistics: the last wave to leave adds the block's sums to one of PRT_STAT_SHARDS copies of the counters
+    unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+#ifdef PRT_PROFILE
+    PROF(tIdle, (void)0);
+    if (lane == 0) {
+        atomicAdd(&C[8], tShade);
+        atomicAdd(&C[9], tTrace);
+        atomicAdd(&C[10], tIdle);
+        atomicAdd(&C[11], nShade);
+        atomicAdd(&C[12], nTrace);
+        atomicAdd(&C[13], t0 - tStart);
+        atomicAdd(&C[14], 1ull);
+    }
+#endif
+    if (lane == 0 && lds_add(&B->exited, 1u) == PRT_BLOCK / 64u - 1u) {
+        wg_acquire();
+        const uint32_t r = lds_ld(&B->rays), o = lds_ld(&B->occl), px = lds_ld(&B->px);
+        if (r) atomicAdd(&C[0], (unsigned long long)r);
+        if (o) atomicAdd(&C[1], (unsigned long long)o);
+        if (px) atomicAdd(&C[6], (unsigned long long)px);
         if (COUNT) {
-            unsigned long long b = tr.nBox, t = tr.nTri, h = tr.nHit, p = tr.nTap;
-#pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                b += (unsigned long long)__shfl_xor((long long)b, o2, 64);
-                t += (unsigned long long)__shfl_xor((long long)t, o2, 64);
-                h += (unsigned long long)__shfl_xor((long long)h, o2, 64);
-                p += (unsigned long long)__shfl_xor((long long)p, o2, 64);
-            }
-            if (lane == 0) {
-                if (b) atomicAdd(&C[2], b);
-                if (t) atomicAdd(&C[3], t);
-                if (h) atomicAdd(&C[4], h);
-                if (p) atomicAdd(&C[5], p);
-            }
+            if (B->nBox) atomicAdd(&C[2], (unsigned long long)B->nBox);
+            if (B->nTri) atomicAdd(&C[3], (unsigned long long)B->nTri);
+            if (B->nHit) atomicAdd(&C[4], (unsigned long long)B->nHit);
+            if (B->nTap) atomicAdd(&C[5], (unsigned long long)B->nTap);
         }
-        if (overflow) atomicAdd(&C[7], 1ull);
+        if (lds_ld(&B->overflow)) atomicAdd(&C[7], 1ull);
     }
 }

@@ -134,14 +134,16 @@ enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 typedef float f4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float4* p)
 {
-    f4_t v = __builtin_nontemporal_load((const f4_t*)p);
+    f4_t v = __builtin_nontemporal_load((const PRT_AS1 f4_t*)p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void nt_store4(float4* p, float4 v)
 {
     f4_t w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, (f4_t*)p);
+    __builtin_nontemporal_store(w, (PRT_AS1 f4_t*)p);
 }
+__device__ __forceinline__ uint32_t nt_load(const uint32_t* p) { return __builtin_nontemporal_load((const PRT_AS1 uint32_t*)p); }
+__device__ __forceinline__ void nt_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, (PRT_AS1 uint32_t*)p); }
 
 struct WfArgs {
     DevScene sc;
@@ -745,6 +747,13 @@ __global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
     uint32_t overflow = 0;
     trace_loop<MODE, COUNT>(A.sc, src, st, tr, overflow);
     unsigned long long* C = A.counters;
+#ifdef PRT_PROFILE
+    if ((tid & 63u) == 0) {
+        atomicAdd(&C[16 + MODE * 3], tr.nBox);
+        atomicAdd(&C[17 + MODE * 3], tr.nTri);
+        atomicAdd(&C[18 + MODE * 3], (unsigned long long)tr.nTap);
+    }
+#endif
     if (COUNT) {
         // 64-bit per-wave sums (a persistent lane can count more than 2^32 box tests)
         unsigned long long b = tr.nBox, t = tr.nTri, p = tr.nTap;
@@ -1525,7 +1534,7 @@ static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalW
     const uint32_t resident = (uint32_t)frame_blocks(c);
     const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(resident, A.totalChunks));
     // a block holds at most rowsPerBlock rows at a time: all of a small launch's rows are in flight at once, spread evenly
-    A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (A.totalChunks + blocks - 1) / blocks));
+    A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, A.totalChunks / blocks));
     int rc = ensure_launch_resources(c, std::max<uint32_t>(resident, (uint32_t)persistent_blocks(c)));
     if (rc) return rc;
     A.spill = c->spill;
@@ -1533,10 +1542,7 @@ static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalW
     if ((rc = frame_layout(c, resident, c->sc.hasEnv != 0, A))) return rc;
     HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), s));
     if (A.totalChunks == 0) return PRT_HIP_OK;
-    // the argument block travels through a small device buffer (one per launch in flight: a ring of PRT_TIMING_RING)
-    if (!c->frameArgs) HIP_TRY(hipMalloc(&c->frameArgs, PRT_TIMING_RING * sizeof(FrameArgs)));
-    FrameArgs* dA = (FrameArgs*)c->frameArgs + (c->frameArgSlot++ % PRT_TIMING_RING);
-    HIP_TRY(hipMemcpyAsync(dA, &A, sizeof(FrameArgs), hipMemcpyHostToDevice, s));
+    const FrameArgs& dA = A;
     const bool env = c->sc.hasEnv != 0;
     if (p->countTraffic) {
         if (env) hipLaunchKernelGGL((frame_kernel<true, true>), dim3(blocks), dim3(PRT_BLOCK), 0, s, dA);
@@ -1824,10 +1830,37 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     }
 #endif
     if (c->frameLaunched) {
-        uint32_t ctrl[2] = {0, 0};
+        uint32_t ctrl[8 + 16 * 8] = {0};
         HIP_TRY(hipMemcpy(ctrl, c->work, sizeof(ctrl), hipMemcpyDeviceToHost));
-        if (ctrl[1]) return fail(PRT_HIP_ELAUNCH, "frame kernel: scheduler watchdog fired (a workgroup waited for work that never came)");
+        if (ctrl[1]) {
+            std::string msg = "frame kernel: scheduler watchdog fired (a workgroup waited for work that never came);";
+            for (uint32_t k = 0; k < std::min<uint32_t>(ctrl[2], 8u); k++) {
+                const uint32_t* D = ctrl + 8 + 16 * k;
+                char line[256];
+                snprintf(line, sizeof(line), " [block %u wave %u: ready %u live %u exhausted %u lock %u, %u groups wait for %u rays, tails %u %u %u %u heads %u %u %u %u]",
+                         D[0], D[1], D[2], D[3], D[4], D[5], D[6], D[7], D[8], D[9], D[10], D[11], D[12], D[13], D[14], D[15]);
+                msg += line;
+            }
+            return fail(PRT_HIP_ELAUNCH, msg);
+        }
     }
+#ifdef PRT_PROFILE
+    if (h[14])
+        fprintf(stderr, "frame profile: waves %llu, per wave: shade %.1f%% (%.0f calls) trace %.1f%% (%.0f calls) idle/decide %.1f%% of %.2f Mcycles\n", h[14],
+                100.0 * h[8] / h[13], (double)h[11] / h[14], 100.0 * h[9] / h[13], (double)h[12] / h[14], 100.0 * h[10] / h[13], h[13] / 1e6 / h[14]);
+    if (!h[14] && h[16 + 3])
+        for (int m = 0; m < 4; m++)
+            fprintf(stderr, "  wavefront trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.0f kcycles per... total %.1f Gcycles in loops => %.0f cycles per turn\n", m,
+                    h[16 + 3 * m] / 1e6, (double)h[17 + 3 * m] / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1), 0.0, h[18 + 3 * m] * 1024.0 / 1e9,
+                    h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
+    if (h[14]) {
+        for (int m = 0; m < 4; m++)
+            fprintf(stderr, "  trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.1f Gcycles in the loops => %.0f cycles per turn\n", m, h[16 + 3 * m] / 1e6,
+                    (double)h[17 + 3 * m] / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1), h[18 + 3 * m] * 1024.0 / 1e9,
+                    h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
+        fprintf(stderr, "  claims %.1f M, empty %.1f M\n", h[28] / 1e6, h[29] / 1e6);
+    }
+#endif
     st->raysTraced = h[0];
     st->occludedTraced = h[1];
     st->nBox = h[2];

@@ -10,11 +10,15 @@ if len(sys.argv) > 1:
     tr = prt_amd.PathTracer(device=0, max_depth=depth, seed=12345)
     tr.upload_scene(scene); tr.set_camera(camera)
     ms = []
-    for i in range(3):
+    for i in range(2):
         tr.render_async(0, 0, W - 1, H - 1, spp, exposure=exposure)
         st = tr.stats()
         ms.append(st["kernelMs"])
-    print(f"{os.path.basename(sys.argv[1])}: {min(ms):.1f} ms  ({st['raysTraced'] / min(ms) / 1e3:.0f} Mray/s)", flush=True)
+    share = []
+    for i in range(2):
+        tr.render_async(0, 0, W - 1, H - 1, spp, exposure=exposure, rank=1, nranks=8)
+        share.append(tr.stats()["kernelMs"])
+    print(f"{os.path.basename(sys.argv[1])} {os.environ.get('PRT_FRAME_BPC', '')}: {min(ms):.1f} ms  ({st['raysTraced'] / min(ms) / 1e3:.0f} Mray/s); 1/8 share {min(share):.1f} ms", flush=True)
     tr.close()
 else:
     var = os.path.join(root, "prt_amd", "lib", "var")
