@@ -24,7 +24,7 @@
 #pragma once
 
 #ifndef PRT_POOL_CHUNKS
-#define PRT_POOL_CHUNKS 8 // rows of 64 pixel groups a block keeps in flight
+#define PRT_POOL_CHUNKS 4 // rows of 64 pixel groups a block keeps in flight
 #endif
 #ifndef PRT_FRAME_WAVES
 #define PRT_FRAME_WAVES 7 // waves per SIMD the frame kernel is compiled for
@@ -38,15 +38,20 @@
 #ifndef PRT_DRAIN_READY
 #define PRT_DRAIN_READY 192u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
 #endif
+#ifndef PRT_SHADE_INLINE
+#define PRT_SHADE_INLINE __noinline__
+#endif
 #ifndef PRT_ROLE_INLINE
 #define PRT_ROLE_INLINE __noinline__
 #endif
 #ifndef PRT_WATCHDOG_SPINS
 #define PRT_WATCHDOG_SPINS (1u << 22) // idle turns (about 0.3 us each) after which a wave gives up: ~1 s
 #endif
+#define PRT_CTRL_CURSORS 256u // ctrl words: [1] watchdog flag, [2] + [8..135] its report, [256 + 32 * band] the 8 row cursors
 #define PRT_CHUNK 64u
 #define PRT_POOL_GROUPS (PRT_POOL_CHUNKS * PRT_CHUNK)
 #define PRT_POOL_SLOTS (PRT_POOL_GROUPS * 8u) // capacity of a block's ray queue per mode: one ray per slot and mode at most
+static_assert((PRT_POOL_SLOTS & (PRT_POOL_SLOTS - 1u)) == 0u, "the ray rings index with a mask: PRT_POOL_CHUNKS must be a power of two");
 #define PEND_DONE 0xffffffffu
 #define PRT_NONE 0xffffffffu
 
@@ -61,9 +66,10 @@ struct FrameArgs {
     uint32_t totalWork;   // pixel groups (tile-major work items) of the launch
     uint32_t totalChunks; // rows of 64 work items
     uint32_t rowsPerBlock; // rows a block may hold at a time (<= PRT_POOL_CHUNKS; fewer when the launch is small)
+    uint32_t spreadRows;   // rows are 8 clusters of 8 work items spread over the launch instead of 64 consecutive items
     float* rgb;
     unsigned long long* counters; // PRT_STAT_SHARDS copies of: rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
-    uint32_t* ctrl;               // [0] row cursor, [1] watchdog flag
+    uint32_t* ctrl;               // row cursors, watchdog flag and report (PRT_CTRL_CURSORS)
     // per pool group (block * PRT_POOL_GROUPS + i)
     uint32_t* gRng;
     uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20 | alive at depth 0 << 24
@@ -89,6 +95,7 @@ struct BlockState { // LDS, one per workgroup
     // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
     uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
     uint32_t pending[PRT_POOL_GROUPS];
+    uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
     uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
     uint32_t lock;      // shade role
@@ -166,6 +173,26 @@ __device__ __forceinline__ const FrameArgs& frame_args(uint64_t bits)
     return *(const FrameArgs*)(FrameKernargs)(((uint64_t)hi << 32) | lo);
 }
 
+// Counting build: a role call's event counts go to the block's 64-bit sums.
+__device__ __forceinline__ void block_count_traffic(BlockLds B, const Traffic& tr)
+{
+    unsigned long long b = tr.nBox, t = tr.nTri, h = tr.nHit, p = tr.nTap;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        b += (unsigned long long)__shfl_xor((long long)b, o, 64);
+        t += (unsigned long long)__shfl_xor((long long)t, o, 64);
+        h += (unsigned long long)__shfl_xor((long long)h, o, 64);
+        p += (unsigned long long)__shfl_xor((long long)p, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        typedef __attribute__((address_space(3))) unsigned long long lds_q;
+        if (b) __hip_atomic_fetch_add((lds_q*)&B->nBox, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t) __hip_atomic_fetch_add((lds_q*)&B->nTri, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (h) __hip_atomic_fetch_add((lds_q*)&B->nHit, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p) __hip_atomic_fetch_add((lds_q*)&B->nTap, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- shade
 // One shade round of up to 8 pixel groups (lanes 8j..8j+7 = the 8 path slots of group j).  P = the group's index into the
 // pool state, PRT_NONE for lanes without a group.  Consumes the hits of the group's last rays, runs the bounce of
@@ -173,9 +200,14 @@ __device__ __forceinline__ const FrameArgs& frame_args(uint64_t bits)
 // who holds the shade lock and publishes them).  Returns, in every lane of the group, the group's new pending word: the
 // number of rays emitted, or PEND_DONE when the pixel has been written.
 template <bool COUNT, bool ENV>
-__device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, uint32_t P, uint32_t poolLocal, uint32_t* blockQ, WaveStats& ws,
-                                               Traffic& tr)
+__device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t poolLocal)
 {
+    // a function of its own: its registers are those of a shade kernel, whatever the caller keeps live around it
+    const FrameArgs& A = frame_args(kargs);
+    const BlockLds B = block_lds();
+    uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
+    WaveStats ws{0, 0, 0};
+    Traffic tr{0, 0, 0, 0};
     const uint32_t lane = threadIdx.x & 63u, slot = lane & 7u, gbase = lane & ~7u;
     const bool inRange = P != PRT_NONE;
     const uint32_t g = inRange ? P : 0u;
@@ -210,6 +242,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
 
     bool needBounce = false, needEnd = false, needCamera = false;
     bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
+    bool statPx = false, statSamples = false;
     uint32_t reverseBits = 0;
 
     if (phase == PH_START) {
@@ -221,12 +254,12 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
                 gst(px, zero);
                 gst(px + 1, zero);
                 gst(px + 2, zero);
-                ws.px++;
-                ws.rays += samples;
+                statPx = true;
+                statSamples = true;
             }
         } else {
             needCamera = true;
-            if (slot == 0) ws.rays += samples; // path_tracer.cpp:62
+            if (slot == 0) statSamples = true; // path_tracer.cpp:62
         }
     } else if (phase == PH_WAIT_PRIMARY) {
         // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
@@ -403,8 +436,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
             emitShadow = true; // the occlusion traversal builds org = pos + kFar*L, dir = -L from the slot's state
             shadowPacket = (alive & 0xfu) > 2u; // :198
             sflags |= SLOT_HAS_SHADOW;
-            ws.rays++;
-            ws.occl++;
+            // (counted below: one ray, one occlusion ray)
         }
         bool survive = active;
         if (depth > rrDepth) { // one draw per alive slot, in slot order
@@ -423,7 +455,6 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
             ndir = normalize3(nextDir); // :267
             emitScatter = true;
             sflags |= SLOT_SURVIVE;
-            ws.rays++;
         }
         phase = PH_WAIT_BOUNCE;
     }
@@ -449,7 +480,7 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
                 gst(px, asu(c.x));
                 gst(px + 1, asu(c.y));
                 gst(px + 2, asu(c.z));
-                ws.px++;
+                statPx = true;
             }
             phase = PH_DONE;
         }
@@ -508,6 +539,19 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
             gst4(&A.gColor[g], make_float4(color.x, color.y, color.z, 0.0f));
         }
     }
+    // ---- statistics (wave-uniform sums: stats.h:10-16; a scatter ray and a shadow ray each count as a ray, path_tracer.cpp:219, 276)
+    {
+        const uint32_t nShadow = (uint32_t)__popcll(__ballot(emitShadow)), nScatter = (uint32_t)__popcll(__ballot(emitScatter));
+        ws.rays = nShadow + nScatter + samples * (uint32_t)__popcll(__ballot(statSamples));
+        ws.occl = nShadow;
+        ws.px = (uint32_t)__popcll(__ballot(statPx));
+        if (lane == 0) {
+            if (ws.rays) lds_add(&B->rays, ws.rays);
+            if (ws.occl) lds_add(&B->occl, ws.occl);
+            if (ws.px) lds_add(&B->px, ws.px);
+        }
+        if (COUNT) block_count_traffic(B, tr);
+    }
     // ---- publish: state and queue entries have to be complete before the pending words, and those before the tails
     const uint32_t np = phase == PH_DONE ? PEND_DONE : emitted;
     wg_release();
@@ -516,26 +560,6 @@ __device__ __forceinline__ uint32_t shade_pass(const FrameArgs& A, BlockLds B, u
     for (int q = 0; q < Q_COUNT; q++)
         if (newTail[q] != 0u && lane == 0u) lds_st_rel(&B->qTail[q], newTail[q]);
     return np;
-}
-
-// Counting build: a role call's event counts go to the block's 64-bit sums.
-__device__ __forceinline__ void block_count_traffic(BlockLds B, const Traffic& tr)
-{
-    unsigned long long b = tr.nBox, t = tr.nTri, h = tr.nHit, p = tr.nTap;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        b += (unsigned long long)__shfl_xor((long long)b, o, 64);
-        t += (unsigned long long)__shfl_xor((long long)t, o, 64);
-        h += (unsigned long long)__shfl_xor((long long)h, o, 64);
-        p += (unsigned long long)__shfl_xor((long long)p, o, 64);
-    }
-    if ((threadIdx.x & 63u) == 0u) {
-        typedef __attribute__((address_space(3))) unsigned long long lds_q;
-        if (b) __hip_atomic_fetch_add((lds_q*)&B->nBox, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (t) __hip_atomic_fetch_add((lds_q*)&B->nTri, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (h) __hip_atomic_fetch_add((lds_q*)&B->nHit, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (p) __hip_atomic_fetch_add((lds_q*)&B->nTap, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- trace
@@ -726,27 +750,39 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
 // ---------------------------------------------------------------------------------------------------------------- roles
 // Shade role (the caller holds the lock): give empty rows new work, then sweep the pending words and run the ready groups.
 template <bool COUNT, bool ENV>
-__device__ PRT_ROLE_INLINE bool shade_role(uint64_t kargs)
+__device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
 {
     const FrameArgs& A = frame_args(kargs);
     const BlockLds B = block_lds();
     const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS;
-    uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     const uint32_t lane = threadIdx.x & 63u;
-    WaveStats ws{0, 0, 0};
-    Traffic tr{0, 0, 0, 0};
     bool did = false;
     // ---- rows whose groups are all done take the next 64 work items
     for (uint32_t row = 0; row < A.rowsPerBlock; row++) {
         if (bcast0(lds_ld(&B->chunkLive[row])) != 0u || bcast0(lds_ld(&B->exhausted)) != 0u) continue;
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&A.ctrl[0], 1u);
+        // Rows come from 8 cursors, one per eighth of the work (a band of the image): a block takes rows from the band of
+        // its own XCD first (blocks b and b + 8 share an XCD and its L2), so that the rays an XCD has in flight come from one
+        // part of the image and its L2 keeps that part of the tree; a block whose band is used up helps with the others.
+        uint32_t c = PRT_NONE;
+        if (lane == 0) {
+            const uint32_t per = (A.totalChunks + 7u) / 8u;
+            for (uint32_t k = 0; k < 8u && c == PRT_NONE; k++) {
+                const uint32_t band = (blockIdx.x + k) & 7u, first = band * per;
+                const uint32_t count = first >= A.totalChunks ? 0u : (A.totalChunks - first < per ? A.totalChunks - first : per);
+                if (gld(&A.ctrl[PRT_CTRL_CURSORS + 32u * band]) >= count) continue; // used up (the counter only grows)
+                const uint32_t got = atomicAdd(&A.ctrl[PRT_CTRL_CURSORS + 32u * band], 1u);
+                if (got < count) c = first + got;
+            }
+        }
         c = bcast0(c);
-        if (c >= A.totalChunks) {
+        if (c == PRT_NONE) {
             if (lane == 0) lds_st(&B->exhausted, 1u);
             break;
         }
-        const uint32_t w = c * PRT_CHUNK + lane;
+        // Work items of row c: 64 consecutive ones (a quarter of a 16x16 tile) -- or, in a launch too small to keep every
+        // block's pool full, 8 clusters of 8 consecutive items taken at equal distances over the whole launch, so that every
+        // row (and with it every block) gets the same mix of cheap and expensive pixels.
+        const uint32_t w = A.spreadRows ? ((c + (lane >> 3) * A.totalChunks) * 8u + (lane & 7u)) : c * PRT_CHUNK + lane;
         const bool valid = w < A.totalWork;
         const uint32_t P = poolBase + row * PRT_CHUNK + lane;
         if (valid) {
@@ -764,50 +800,41 @@ __device__ PRT_ROLE_INLINE bool shade_role(uint64_t kargs)
             lds_add(&B->ready, n);
         }
         did = true;
+        break; // one row per call: the blocks of a small launch all start at once, so its rows spread evenly over them
     }
     wg_release(); // the group headers above are read back below (other lanes of this wave) and by later shade rounds
-    // ---- sweep
+    // ---- sweep: collect the ready groups of all rows (ballot + popcount rank into a list in LDS), then run them 8 per pass
+    uint32_t n = 0;
     for (uint32_t row = 0; row < PRT_POOL_CHUNKS; row++) {
         if (bcast0(lds_ld(&B->chunkLive[row])) == 0u) continue;
-        for (uint32_t guard = 0; guard < 4096u; guard++) {
-            const uint32_t v = lds_ld_acq(&B->pending[row * PRT_CHUNK + lane]);
-            unsigned long long m = __ballot(v == 0u);
-            if (m == 0ull) break;
-            // up to 8 ready groups: lanes 8j..8j+7 take the j-th set bit
-            uint32_t gi = PRT_NONE, taken = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
-                if (m == 0ull) break;
-                const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1ull;
-                if ((lane >> 3) == j) gi = b;
-                taken++;
-            }
-            const uint32_t local = gi != PRT_NONE ? row * PRT_CHUNK + gi : 0u;
-            const uint32_t np = shade_pass<COUNT, ENV>(A, B, gi != PRT_NONE ? poolBase + local : PRT_NONE, local, blockQ, ws, tr);
-            // (shade_pass has published the groups' state, their pending words and the queue tails, in that order)
-            const bool head = gi != PRT_NONE && (lane & 7u) == 0u;
-            const uint32_t nDone = (uint32_t)__popcll(__ballot(head && np == PEND_DONE));
-            const uint32_t nAgain = (uint32_t)__popcll(__ballot(head && np == 0u));
-            if (lane == 0) {
-                if (nDone) {
-                    lds_sub(&B->chunkLive[row], nDone);
-                    lds_sub(&B->live, nDone);
-                }
-                lds_sub(&B->ready, taken - nAgain);
-            }
-            did = true;
-        }
+        const uint32_t v = lds_ld_acq(&B->pending[row * PRT_CHUNK + lane]);
+        const unsigned long long m = __ballot(v == 0u);
+        if (v == 0u) lds_st(&B->readyList[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))], row * PRT_CHUNK + lane);
+        n += (uint32_t)__popcll(m);
     }
-    // ---- this call's statistics to the block
-    {
-        const uint32_t r = wave_sum(ws.rays), o = wave_sum(ws.occl), px = wave_sum(ws.px);
+    for (uint32_t i = 0; i < n; i += 8u) {
+        const uint32_t j = i + (lane >> 3);
+        const bool has = j < n;
+        const uint32_t local = has ? lds_ld(&B->readyList[j]) : 0u;
+        const uint32_t np = shade_pass<COUNT, ENV>(kargs, has ? poolBase + local : PRT_NONE, local);
+        // (shade_pass has published the groups' state, their pending words and the queue tails, in that order)
+        const bool head = has && (lane & 7u) == 0u;
+        const bool done = head && np == PEND_DONE;
+        if (done) lds_sub(&B->chunkLive[local >> 6], 1u);
+        const uint32_t taken = n - i < 8u ? n - i : 8u;
+        const uint32_t nDone = (uint32_t)__popcll(__ballot(done)), nAgain = (uint32_t)__popcll(__ballot(head && np == 0u));
         if (lane == 0) {
-            if (r) lds_add(&B->rays, r);
-            if (o) lds_add(&B->occl, o);
-            if (px) lds_add(&B->px, px);
+            if (nDone) lds_sub(&B->live, nDone);
+            lds_sub(&B->ready, taken - nAgain);
         }
-        if (COUNT) block_count_traffic(B, tr);
+#ifdef PRT_PROFILE
+        if (lane == 0) {
+            unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+            atomicAdd(&C[30], 1ull);
+            atomicAdd(&C[31], (unsigned long long)taken);
+        }
+#endif
+        did = true;
     }
     return did;
 }

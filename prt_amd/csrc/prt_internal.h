@@ -21,7 +21,7 @@
 #ifndef PRT_PARTS
 #define PRT_PARTS 2 // independent pipelines a pass is dealt to
 #endif
-#define PRT_WORK_WORDS 128 // queue counters of one pipeline (4 + Q_COUNT * PRT_QSHARDS used)
+#define PRT_WORK_WORDS 512 // control words per pipeline (wavefront pipeline: 4 + Q_COUNT * PRT_QSHARDS; frame kernel: PRT_CTRL_CURSORS)
 #define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
 #define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
 #define PRT_TIMING_RING 32

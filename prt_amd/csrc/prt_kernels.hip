@@ -134,13 +134,21 @@ enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
 typedef float f4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float4* p)
 {
+#ifdef PRT_STATE_PLAIN
+    return gld4(p);
+#else
     f4_t v = __builtin_nontemporal_load((const PRT_AS1 f4_t*)p);
     return make_float4(v.x, v.y, v.z, v.w);
+#endif
 }
 __device__ __forceinline__ void nt_store4(float4* p, float4 v)
 {
+#ifdef PRT_STATE_PLAIN
+    gst4(p, v);
+#else
     f4_t w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, (PRT_AS1 f4_t*)p);
+#endif
 }
 __device__ __forceinline__ uint32_t nt_load(const uint32_t* p) { return __builtin_nontemporal_load((const PRT_AS1 uint32_t*)p); }
 __device__ __forceinline__ void nt_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, (PRT_AS1 uint32_t*)p); }
@@ -1533,8 +1541,11 @@ static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalW
     A.ctrl = c->work;
     const uint32_t resident = (uint32_t)frame_blocks(c);
     const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(resident, A.totalChunks));
-    // a block holds at most rowsPerBlock rows at a time: all of a small launch's rows are in flight at once, spread evenly
-    A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, A.totalChunks / blocks));
+    // a block holds at most rowsPerBlock rows at a time and takes one row per visit to the shade role: all of a small launch's
+    // rows are in flight at once (a row that starts late costs a whole chain of rounds), spread evenly over the blocks
+    A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (A.totalChunks + blocks - 1) / blocks));
+    A.spreadRows = (A.totalChunks < (uint64_t)blocks * PRT_POOL_CHUNKS * 2 && totalWork % PRT_CHUNK == 0) ? 1u : 0u;
+    if (const char* e = getenv("PRT_SPREAD")) A.spreadRows = atoi(e) && totalWork % PRT_CHUNK == 0;
     int rc = ensure_launch_resources(c, std::max<uint32_t>(resident, (uint32_t)persistent_blocks(c)));
     if (rc) return rc;
     A.spill = c->spill;
@@ -1858,7 +1869,7 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
             fprintf(stderr, "  trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.1f Gcycles in the loops => %.0f cycles per turn\n", m, h[16 + 3 * m] / 1e6,
                     (double)h[17 + 3 * m] / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1), h[18 + 3 * m] * 1024.0 / 1e9,
                     h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
-        fprintf(stderr, "  claims %.1f M, empty %.1f M\n", h[28] / 1e6, h[29] / 1e6);
+        fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));
     }
 #endif
     st->raysTraced = h[0];
