@@ -28,12 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The pipeline keeps four streams busy at once; with RCCL's own streams in the process the HIP runtime's default of four
-# hardware queues makes them share queues (measured: 647 ms instead of 594 ms per C3 frame).  Must be set before the
-# runtime initialises, i.e. before the first HIP call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 WORKLOADS = {
     # name: (setup function name, kwargs, width, height, spp, maxDepth, description)

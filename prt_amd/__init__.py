@@ -11,9 +11,6 @@ Reference citations (file:line under /root/reference/src) are in include/prt_hip
 import ctypes as C
 import os
 
-# see prt_hip_create: more hardware queues when the process also runs RCCL / framework streams (read at HIP runtime start-up)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 import numpy as np
 
 from . import _build

@@ -809,9 +809,6 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
     const uint32_t waveId = blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t staticEnd = totalWaves * chunk;
     uint32_t rangeNext = waveId * chunk, rangeEnd = rangeNext + chunk;
-#ifdef PRT_PROFILE
-    unsigned long long pTurns = 0, pLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
-#endif
     for (;;) {
         unsigned long long need = __ballot(!active && !exhausted);
         if (need) {
@@ -851,10 +848,6 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
             }
         }
         if (!__any(active)) break;
-#ifdef PRT_PROFILE
-        pTurns++;
-        pLanes += (unsigned long long)__popcll(__ballot(active));
-#endif
         if (active && T.ref == PRT_REF_NONE) {
             if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
                 if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
@@ -868,11 +861,6 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
         }
         trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
-#ifdef PRT_PROFILE
-    tr.nBox = pTurns; // diagnostic build: the traffic counters carry the loop statistics out (profile builds never count traffic)
-    tr.nTri = pLanes;
-    tr.nTap = (uint32_t)((__builtin_amdgcn_s_memtime() - pT0) >> 10);
-#endif
 }
 
 // ---------------------------------------------------------------------------- surface + material

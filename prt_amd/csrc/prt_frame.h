@@ -32,6 +32,9 @@
 #ifndef PRT_SHADE_MIN
 #define PRT_SHADE_MIN 16u // ready groups that make a wave at a decision point take the shade role
 #endif
+#ifndef PRT_TRACE_PRIO
+#define PRT_TRACE_PRIO 1
+#endif
 #ifndef PRT_CLAIM
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
@@ -595,6 +598,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     uint32_t heldNext = 0, heldEnd = 0; // which of them are left (wave-uniform)
 #pragma unroll
     for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) held[j] = 0;
+    __builtin_amdgcn_s_setprio(PRT_TRACE_PRIO); // tracing waves sit on dependent loads: they issue first, shading fills in
 #ifdef PRT_PROFILE
     unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pT0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -735,6 +739,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     }
     if (overflow) lds_st(&B->overflow, 1u);
     if (COUNT) block_count_traffic(B, tr);
+    __builtin_amdgcn_s_setprio(0);
 #ifdef PRT_PROFILE
     if (lane == 0) {
         unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;

@@ -110,25 +110,17 @@ struct Surf5 { // what moves between slots at a compaction
     uint32_t mat, prim;
 };
 
-// ============================================================================ wavefront pipeline
-// The per-pixel loop of the reference is run as a state machine over ALL pixel groups at once (DESIGN.md "Kernels"):
-//
-//   shade_kernel   8 lanes per pixel group (one lane per path slot).  Consumes the hits of the previous iteration
-//                  (gathering alive paths into slots 0..n-1 by ballot/prefix rank), runs the bounce phase of
-//                  path_tracer.cpp:124-293 (RNG draws by prefix-counted stepping of the shared xorshift state, BSDF
-//                  direction, Russian roulette) and EMITS the rays of the next iteration into per-mode queues, packed
-//                  by wave ballot + prefix sum + one atomic per wave.
-//   trace_kernel   one lane per queued ray, one instantiation per traversal mode (primary packet rays, scatter
-//                  rays, packet / single occlusion rays), results written back to the owner slot.
-//
-// One iteration = shade + 4 traces; a packet needs 1 + maxDepth iterations, so an image needs
-// (samples/8)*(1+maxDepth)+1 iterations, enqueued back to back without host synchronisation.
+// ============================================================================ the per-pixel loop
+// The loop of the reference is run as a state machine over pixel groups (a group = the 8 path slots of one pixel, one lane
+// each); one round of a group = a shade pass (consume the hits of its last rays, run the bounce of path_tracer.cpp:124-293,
+// emit the next rays) followed by the traversal of those rays.  A packet needs 1 + maxDepth rounds, a pixel
+// (samples/8)*(1+maxDepth)+1.  Scheduling, queues and kernels: prt_frame.h.
 enum { Q_PRIMARY = PRT_MODE_PACKET, Q_SCATTER = PRT_MODE_SINGLE, Q_OCC_PACKET = PRT_MODE_OCC_PACKET, Q_OCC_SINGLE = PRT_MODE_OCC_SINGLE, Q_COUNT = 4 };
 enum { PH_START = 0, PH_WAIT_PRIMARY = 1, PH_WAIT_BOUNCE = 2, PH_DONE = 3 };
-#define PRT_QSHARDS 16
 #define SLOT_HAS_SHADOW 1u
 #define SLOT_SURVIVE 2u
 #define SLOT_LIGHT_SET 4u
+
 
 // streaming (touch-once-per-iteration) state goes around the caches' retention so that the BVH stays resident
 typedef float f4_t __attribute__((ext_vector_type(4)));
@@ -152,633 +144,6 @@ __device__ __forceinline__ void nt_store4(float4* p, float4 v)
 }
 __device__ __forceinline__ uint32_t nt_load(const uint32_t* p) { return __builtin_nontemporal_load((const PRT_AS1 uint32_t*)p); }
 __device__ __forceinline__ void nt_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, (PRT_AS1 uint32_t*)p); }
-
-struct WfArgs {
-    DevScene sc;
-    DevCamera cam;
-    prt_render_params p;
-    uint32_t x0, y0, x1, y1;
-    uint32_t tilesXImage;
-    uint32_t rtx0, rty0, rtnx, rtny;
-    uint32_t fullWidth, firstOwned;
-    uint32_t workBase;   // first work item (tile-major pixel index) of this pass, a multiple of the tile area
-    uint32_t partIndex, partCount; // the pass is dealt to partCount independent pipelines tile by tile; this is pipeline partIndex
-    uint32_t groupCount; // pixel groups in this pass
-    float* rgb;
-    unsigned long long* counters; // rays, occl, nBox, nTri, nHit, nTap, nPx, overflow
-    // per group
-    uint32_t* gRng;
-    uint32_t* gInfo;  // packet | depth << 8 | alive << 16 | phase << 20 | alive at depth 0 << 24
-    uint32_t* gPixel; // x | y << 16, 0xffffffff = no pixel (outside the rectangle / not this rank's tile)
-    float4* gColor;
-    // per slot (8 per group): what a path carries from one iteration to the next (68 B)
-    float4* S0; // pos.xyz, bits(material of the surface the path stands on)
-    float4* S1; // shading normal xyz, bits(slot flags)
-    float4* S2; // direction of the ray in flight (primary or scatter) xyz
-    float4* S3; // beta.xyz
-    float4* S4; // result.xyz -- belongs to the SLOT, not the path: it stays behind when the path dies or is compacted away
-    float4* S5; // environment light only: lightDir[slot].xyz      (path_tracer.cpp:125; like result, it belongs to the slot and
-    float4* S6; //                         lightIntensity[slot].xyz  keeps its last value while the packet lives)
-    float4* hitA;   // t i j k
-    uint2* hitB;    // primId meshId
-    uint32_t* occl; // 1 = occluded
-    // ray queues
-    uint32_t* qE[Q_COUNT]; // queued ray = owner slot (26 bits) | reverseBits << 26 | lightSet << 29; the trace kernels rebuild
-                           // the ray from the owner's state
-    // Queue q is split into PRT_QSHARDS regions of shardCap entries; blocks append to region blockIdx % PRT_QSHARDS, so that
-    // the returning atomics that reserve space are spread over 16 addresses per queue (one address takes ~88 of them
-    // per microsecond, MI355X_MICROARCH.md "dequeue").  qWork: [0..3] claim cursors of the trace kernels,
-    // [4 + q*PRT_QSHARDS + shard] entries in that region.
-    uint32_t* qWork;
-    uint32_t shardCap;
-    uint32_t* spill;
-    uint32_t spillStride;
-};
-
-// Diagnostic build (-DPRT_STAMP): per-segment wave time of the shade kernel, summed into counters[8..15].
-#ifdef PRT_STAMP
-#define STAMP(k)                                                                                    \
-    do {                                                                                            \
-        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                       \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
-        stampAcc[k] += t_ - stampLast;                                                              \
-        stampLast = t_;                                                                             \
-    } while (0)
-#else
-#define STAMP(k)
-#endif
-
-template <bool COUNT, bool ENV>
-__global__ __launch_bounds__(PRT_BLOCK, PRT_SHADE_WAVES) void shade_kernel(WfArgs A)
-{
-#ifdef PRT_STAMP
-    unsigned long long stampAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, slot = lane & 7u, gbase = lane & ~7u;
-    const uint32_t g = (blockIdx.x * PRT_BLOCK + tid) >> 3;
-    const bool inRange = g < A.groupCount; // whole groups are in or out together
-    const uint32_t gs = (inRange ? g : 0u) * 8u + slot;
-    const DevScene& sc = A.sc;
-    const DevCamera& cam = A.cam;
-    const uint32_t samples = A.p.samples, maxDepth = A.p.maxDepth, rrDepth = A.p.rrDepth, packets = samples / 8u;
-    const float kPi = 3.14159265358979323846f;
-    const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
-    const float kEpsilon = 0.0008f;      // :193
-    const uint32_t lowerMask = (1u << slot) - 1u;
-
-    Traffic tr{0, 0, 0, 0};
-    unsigned long long nRays = 0, nOccl = 0, nPx = 0;
-
-    uint32_t info = inRange ? A.gInfo[g] : ((uint32_t)PH_DONE << 20);
-    uint32_t phase = (info >> 20) & 0xfu, pk = info & 0xffu, depth = (info >> 8) & 0xffu, alive = (info >> 16) & 0xfu;
-    uint32_t alive0 = (info >> 24) & 0xfu; // slots that have held a path in this packet: the others' result is still 0
-    const uint32_t aliveAtEntry = (phase == PH_WAIT_BOUNCE) ? alive : 0u;
-    uint32_t rng = 0, pixel = 0xffffffffu;
-    Vec3 color = mk3(0, 0, 0);
-    if (inRange) { // with gInfo, not after it: one round trip (a finished group reads three words it will not use)
-        rng = A.gRng[g];
-        pixel = A.gPixel[g];
-        float4 c = A.gColor[g];
-        color = mk3(c.x, c.y, c.z);
-    }
-    const uint32_t x = pixel & 0xffffu, y = pixel >> 16;
-    STAMP(0);
-
-    // slot state
-    Vec3 pos = mk3(0, 0, 0), rayDir = mk3(0, 0, 0), normal = mk3(0, 0, 0), beta = mk3(1, 1, 1), result = mk3(0, 0, 0), ndir = mk3(0, 0, 0);
-    Surface props{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-    uint32_t material = 0, sflags = 0, lightSet = 0;
-    Vec3 envL = mk3(0, 0, 0), envI = mk3(0, 0, 0); // ENV: this bounce's sampled light, when the slot samples one
-    bool envSampled = false;
-
-    bool needBounce = false, needEnd = false, needCamera = false;
-    bool emitPrimary = false, emitShadow = false, emitScatter = false, shadowPacket = false;
-    uint32_t reverseBits = 0;
-
-    if (phase == PH_START) {
-        if (pixel == 0xffffffffu || packets == 0u) {
-            phase = PH_DONE;
-            if (pixel != 0xffffffffu && slot == 0) { // samples < 8: the reference still writes 0/samples
-                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
-                px[0] = px[1] = px[2] = A.p.exposure * (0.0f / (float)samples);
-                nPx++;
-                nRays += samples;
-            }
-        } else {
-            needCamera = true;
-            if (slot == 0) nRays += samples; // path_tracer.cpp:62
-        }
-    } else if (phase == PH_WAIT_PRIMARY) {
-        // ---- ComputeRadiance set-up (path_tracer.cpp:81-120): hits gathered into slots 0..alive-1 in lane order
-        float4 ha = nt_load4(&A.hitA[gs]);
-        uint2 hb = A.hitB[gs];
-        float4 s2 = nt_load4(&A.S2[gs]); // the primary ray's direction
-        Vec3 pdir = mk3(s2.x, s2.y, s2.z), porg = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
-        DevHit h{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
-        bool isHit = h.t != -1.0f;
-        Surf5 sv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-        Vec3 snormal = mk3(0, 0, 0), spos = mk3(0, 0, 0);
-        if (isHit) {
-            Surface s;
-            get_surface<COUNT>(sc, h, s, tr);
-            sv = Surf5{s.normal, s.uv, s.mat, s.prim};
-            snormal = sample_bump<COUNT>(sc, s.mat, s, tr);
-            spos = add3(scale3(h.t, pdir), porg);
-        }
-        uint32_t hm = group_ballot(isHit, gbase);
-        alive = __popc(hm);
-        uint32_t src = gbase + ((slot < alive) ? nth_set(hm, slot) : slot);
-        props.normal = sh3(sv.normal, src);
-        props.uv = Vec2{shf(sv.uv.x, src), shf(sv.uv.y, src)};
-        props.mat = shu(sv.mat, src);
-        props.prim = shu(sv.prim, src);
-        material = props.mat;
-        normal = sh3(snormal, src);
-        pos = sh3(spos, src);
-        rayDir = sh3(pdir, src);
-        beta = mk3(1.0f, 1.0f, 1.0f);
-        result = mk3(0.0f, 0.0f, 0.0f);
-        lightSet = 0;
-        depth = 0;
-        alive0 = alive;
-        if (alive != 0u && depth < maxDepth) needBounce = true;
-        else needEnd = true;
-    } else if (phase == PH_WAIT_BOUNCE) {
-        uint32_t pmat = 0;
-        if (slot < alive) { // dead slots carry nothing
-            float4 s0 = nt_load4(&A.S0[gs]), s1 = nt_load4(&A.S1[gs]), s2 = nt_load4(&A.S2[gs]), s3 = nt_load4(&A.S3[gs]);
-            pos = mk3(s0.x, s0.y, s0.z);
-            pmat = asu(s0.w);
-            normal = mk3(s1.x, s1.y, s1.z);
-            sflags = asu(s1.w);
-            ndir = mk3(s2.x, s2.y, s2.z);
-            beta = mk3(s3.x, s3.y, s3.z);
-            float4 s4 = nt_load4(&A.S4[gs]);
-            result = mk3(s4.x, s4.y, s4.z);
-        }
-        props.mat = pmat;
-        lightSet = (sflags & SLOT_LIGHT_SET) ? 1u : 0u;
-#ifdef PRT_STAMP
-        asm volatile("" ::"v"(pos.x), "v"(beta.x), "v"(result.x));
-        __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0): the state loads have landed
-#endif
-        STAMP(6);
-        // ---- light contribution of the previous bounce (path_tracer.cpp:226-231, 246-249)
-        if (sflags & SLOT_HAS_SHADOW) {
-            if (A.occl[gs] == 0u) {
-                Vec3 lightDir = mk3(0, 0, 0), lightInt = mk3(0, 0, 0);
-                if (lightSet) {
-                    if (ENV) {
-                        float4 l5 = nt_load4(&A.S5[gs]), l6 = nt_load4(&A.S6[gs]);
-                        lightDir = mk3(l5.x, l5.y, l5.z);
-                        lightInt = mk3(l6.x, l6.y, l6.z);
-                    } else {
-                        lightDir = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
-                        lightInt = mk3(sc.lightIntensity[0], sc.lightIntensity[1], sc.lightIntensity[2]);
-                    }
-                }
-                Vec3 lr = div3s(scale3(std_max(dot3(lightDir, normal), 0.0f), lightInt), kPi);
-                result = add3(result, mul3(beta, lr));
-            }
-        }
-        // ---- scatter hits, ordered compaction into slot ci (path_tracer.cpp:281-293)
-        bool hitNext = false;
-        Surface ns{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-        Vec3 npos = mk3(0, 0, 0);
-        if (sflags & SLOT_SURVIVE) {
-            float4 ha = nt_load4(&A.hitA[gs]);
-            uint2 hb = A.hitB[gs];
-            DevHit nh{ha.x, ha.y, ha.z, ha.w, hb.x, hb.y};
-            if (nh.t != -1.0f) {
-                hitNext = true;
-                get_surface<COUNT>(sc, nh, ns, tr);
-                npos = add3(scale3(nh.t, ndir), pos);
-            }
-        }
-#ifdef PRT_STAMP
-        asm volatile("" ::"v"(npos.x), "v"(ns.normal.x));
-        __builtin_amdgcn_s_waitcnt(0x0070);
-#endif
-        STAMP(7);
-        uint32_t nm = group_ballot(hitNext, gbase);
-        uint32_t nAlive = __popc(nm);
-        if (nAlive == 0u) {
-            needEnd = true; // path_tracer.cpp:295
-        } else {
-            uint32_t ci = __popc(nm & lowerMask);
-            uint32_t smat = 0;
-            Vec3 snorm = mk3(0, 0, 0);
-            Surf5 nv{mk3(0, 0, 0), Vec2{0, 0}, 0, 0};
-            if (hitNext) {
-                // materials[ci] = props[i].material reads the slot's PREVIOUS surface unless ci == i (:286-288)
-                smat = (ci == slot) ? ns.mat : props.mat;
-                snorm = sample_bump<COUNT>(sc, smat, ns, tr);
-                nv = Surf5{ns.normal, ns.uv, ns.mat, ns.prim};
-            }
-            // beta[ci] = beta[i]/(1-q) is only written under Russian roulette (:263); q is a function of beta
-            Vec3 betaNew = beta;
-            if (depth > rrDepth) {
-                float q = std_max(0.05f, 1.0f - length3(beta));
-                betaNew = div3s(beta, 1.0f - q);
-            }
-#ifdef PRT_STAMP
-            asm volatile("" ::"v"(snorm.x));
-            __builtin_amdgcn_s_waitcnt(0x0070);
-#endif
-            STAMP(8);
-            uint32_t src2 = gbase + ((slot < nAlive) ? nth_set(nm, slot) : slot);
-            props.normal = sh3(nv.normal, src2);
-            props.uv = Vec2{shf(nv.uv.x, src2), shf(nv.uv.y, src2)};
-            props.mat = shu(nv.mat, src2);
-            props.prim = shu(nv.prim, src2);
-            material = shu(smat, src2);
-            normal = sh3(snorm, src2);
-            pos = sh3(npos, src2);
-            rayDir = sh3(ndir, src2);
-            Vec3 bmoved = sh3(betaNew, src2);
-            if (depth > rrDepth && slot < nAlive) beta = bmoved;
-            alive = nAlive;
-            depth++;
-            if (depth < maxDepth) needBounce = true;
-            else needEnd = true;
-        }
-    }
-
-    STAMP(1);
-    if (needBounce) {
-        // ---- one bounce (path_tracer.cpp:131-190 and the Russian roulette of :258-265)
-        const bool active = slot < alive;
-        uint32_t rtype = 2u;
-        if (active) {
-            const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)material;
-            float4 m0 = mp[0], m1 = mp[1];
-            rtype = asu(m0.w);
-            if (m1.x != 0.0f) result = add3(result, mul3(beta, mk3(m1.x, m1.y, m1.z))); // :137-139
-        }
-        const bool draws = active && (rtype == 0u || rtype == 1u);
-        uint32_t dm = group_ballot(draws, gbase);
-        uint32_t pre = 2u * __popc(dm & lowerMask), tot = 2u * __popc(dm);
-        if (ENV) { // a diffuse slot draws two more for InfiniteAreaLight::sample (:164-167), after its r2, r1
-            uint32_t em = group_ballot(active && rtype == 0u, gbase);
-            pre += 2u * __popc(em & lowerMask);
-            tot += 2u * __popc(em);
-        }
-        uint32_t s = rng, r2b = 0, r1b = 0, uxb = 0, uyb = 0;
-        for (uint32_t j = 0; j < tot; j++) {
-            s = xorshift32(s);
-            if (j == pre) r2b = s;
-            if (j == pre + 1u) r1b = s;
-            if (ENV && j == pre + 2u) uxb = s;
-            if (ENV && j == pre + 3u) uyb = s;
-        }
-        rng = s;
-        STAMP(9);
-        Vec3 nextDir = mk3(0, 0, 0);
-        bool wantLight = false;
-        if (draws) {
-            Vec3 dd = diffuse_dir(normal, rng_to_float(r2b), rng_to_float(r1b));
-            if (rtype == 0u) {
-                nextDir = dd;
-                beta = mul3(beta, sample_diffuse<COUNT>(sc, material, props.uv, tr)); // :162
-                if (ENV) { // :164-167
-                    env_sample<COUNT>(sc, rng_to_float(uxb), rng_to_float(uyb), envL, envI, tr);
-                    envSampled = true;
-                    lightSet = 1u;
-                    wantLight = true;
-                } else if (sc.hasLight) { // :168-172
-                    lightSet = 1u;
-                    wantLight = true;
-                }
-            } else {
-                Vec3 reflectDir = sub3(rayDir, scale3(dot3(normal, rayDir), scale3(2.0f, normal))); // :186
-                nextDir = add3(scale3(0.9f, reflectDir), scale3(0.1f, dd));
-            }
-        }
-#ifdef PRT_STAMP
-        asm volatile("" ::"v"(nextDir.x), "v"(beta.x));
-        __builtin_amdgcn_s_waitcnt(0x0070);
-#endif
-        STAMP(10);
-        const bool directLighting = group_ballot(wantLight, gbase) != 0u;
-        sflags = 0;
-        if (directLighting && active) { // :196-252: every alive path gets an occlusion ray
-            emitShadow = true; // the occlusion kernels build org = pos + kFar*L, dir = -L from the slot's state
-            shadowPacket = (alive & 0xfu) > 2u; // :198
-            sflags |= SLOT_HAS_SHADOW;
-            nRays++;
-            nOccl++;
-        }
-        bool survive = active;
-        if (depth > rrDepth) { // one draw per alive slot, in slot order
-            uint32_t s2 = rng, ub = 0;
-            for (uint32_t j = 0; j < alive; j++) {
-                s2 = xorshift32(s2);
-                if (j == slot) ub = s2;
-            }
-            rng = s2;
-            if (active) {
-                float q = std_max(0.05f, 1.0f - length3(beta));
-                if (rng_to_float(ub) < q) survive = false;
-            }
-        }
-        if (survive) {
-            ndir = normalize3(nextDir); // :267
-            emitScatter = true;
-            sflags |= SLOT_SURVIVE;
-            nRays++;
-        }
-        phase = PH_WAIT_BOUNCE;
-    }
-
-    STAMP(2);
-    if (needEnd) {
-        // ---- Σ result[0..7] in slot order (path_tracer.cpp:303-307), color += (:71).  Slots whose path ended in an earlier
-        // iteration left their result in memory.
-        if (slot >= aliveAtEntry && slot < alive0 && phase == PH_WAIT_BOUNCE) {
-            float4 s4 = nt_load4(&A.S4[gs]);
-            result = mk3(s4.x, s4.y, s4.z);
-        }
-        Vec3 res = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (uint32_t l = 0; l < 8; l++) res = add3(res, sh3(result, gbase + l));
-        color = add3(color, res);
-        pk++;
-        if (pk < packets) {
-            needCamera = true;
-        } else {
-            Vec3 c = scale3(A.p.exposure, div3s(color, (float)samples)); // path_tracer.cpp:28, image.cpp:45
-            if (slot == 0) {
-                float* px = A.rgb + ((size_t)x + (size_t)y * cam.width) * 3;
-                px[0] = c.x;
-                px[1] = c.y;
-                px[2] = c.z;
-                nPx++;
-            }
-            phase = PH_DONE;
-        }
-    }
-
-    if (needCamera) {
-        DevRay pr;
-        Vec3 avgDir;
-        camera_packet(cam, rng, x, y, slot, gbase, pr, avgDir);
-        reverseBits = (avgDir.x < 0.0f ? 1u : 0u) | (avgDir.y < 0.0f ? 2u : 0u) | (avgDir.z < 0.0f ? 4u : 0u);
-        ndir = pr.dir;
-        emitPrimary = true;
-        phase = PH_WAIT_PRIMARY;
-    }
-
-    STAMP(3);
-    // ---- converged part: pack the rays of the next iteration into the queues.  Lane rank by wave ballot + popcount,
-    // wave offset by an LDS atomic, one global (returning) atomic per block and queue on the block's shard.
-    {
-        __shared__ uint32_t blkCount[Q_COUNT], blkBase[Q_COUNT];
-        if (tid < Q_COUNT) blkCount[tid] = 0;
-        __syncthreads();
-        const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
-        uint32_t waveOff[Q_COUNT], rank[Q_COUNT];
-#pragma unroll
-        for (int q = 0; q < Q_COUNT; q++) {
-            unsigned long long mask = __ballot(want[q]);
-            rank[q] = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            uint32_t off = 0;
-            if (mask != 0ull && lane == 0) off = atomicAdd(&blkCount[q], (uint32_t)__popcll(mask));
-            waveOff[q] = shu(off, 0);
-        }
-        __syncthreads();
-        STAMP(11);
-        const uint32_t shard = blockIdx.x % PRT_QSHARDS;
-        if (tid < Q_COUNT && blkCount[tid] != 0u) blkBase[tid] = atomicAdd(&A.qWork[4 + tid * PRT_QSHARDS + shard], blkCount[tid]);
-        __syncthreads();
-        STAMP(12);
-        const uint32_t owner = gs;
-#pragma unroll
-        for (int q = 0; q < Q_COUNT; q++) {
-            if (!want[q]) continue;
-            uint32_t idx = shard * A.shardCap + blkBase[q] + waveOff[q] + rank[q];
-            uint32_t bits = owner | (q == Q_PRIMARY ? (reverseBits << 26) : 0u) | (q >= Q_OCC_PACKET ? (lightSet << 29) : 0u);
-            __builtin_nontemporal_store(bits, &A.qE[q][idx]);
-        }
-    }
-
-    STAMP(4);
-    // ---- store state
-    if (inRange && ((info >> 20) & 0xfu) != PH_DONE) {
-        if (phase == PH_WAIT_BOUNCE && slot < alive) {
-            nt_store4(&A.S0[gs], make_float4(pos.x, pos.y, pos.z, asf(props.mat)));
-            nt_store4(&A.S1[gs], make_float4(normal.x, normal.y, normal.z, asf(sflags | (lightSet ? SLOT_LIGHT_SET : 0u))));
-            nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
-            nt_store4(&A.S3[gs], make_float4(beta.x, beta.y, beta.z, 0.0f));
-            if (ENV && envSampled) {
-                nt_store4(&A.S5[gs], make_float4(envL.x, envL.y, envL.z, 0.0f));
-                nt_store4(&A.S6[gs], make_float4(envI.x, envI.y, envI.z, 0.0f));
-            }
-        }
-        // a slot's result is stored while the slot is alive and once more in the iteration its path ends
-        if (phase == PH_WAIT_BOUNCE && slot < (aliveAtEntry > alive ? aliveAtEntry : alive))
-            nt_store4(&A.S4[gs], make_float4(result.x, result.y, result.z, 0.0f));
-        if (phase == PH_WAIT_PRIMARY) nt_store4(&A.S2[gs], make_float4(ndir.x, ndir.y, ndir.z, 0.0f));
-        if (slot == 0) {
-            A.gInfo[g] = (pk & 0xffu) | ((depth & 0xffu) << 8) | ((alive & 0xfu) << 16) | (phase << 20) | ((alive0 & 0xfu) << 24);
-            A.gRng[g] = rng;
-            A.gColor[g] = make_float4(color.x, color.y, color.z, 0.0f);
-        }
-    }
-    STAMP(5);
-#ifdef PRT_STAMP
-    if (lane == 0)
-        for (int k = 0; k < 13; k++) atomicAdd(&A.counters[8 + k], stampAcc[k]);
-    if (lane == 0) atomicAdd(&A.counters[23], 1ull);
-#endif
-    // ---- statistics: block-level sums in LDS, then one atomic per block and counter on one of PRT_STAT_SHARDS copies
-    // (per-wave atomics on ONE address would be ~0.5 M same-address atomics per launch; they serialise at the memory side)
-    {
-        __shared__ uint32_t blkStat[5];
-        if (tid < 5) blkStat[tid] = 0;
-        __syncthreads();
-        uint32_t r = wave_sum((uint32_t)nRays), o = wave_sum((uint32_t)nOccl), px = wave_sum((uint32_t)nPx);
-        uint32_t nh = COUNT ? wave_sum(tr.nHit) : 0u, nt = COUNT ? wave_sum(tr.nTap) : 0u;
-        if (lane == 0) {
-            if (r) atomicAdd(&blkStat[0], r);
-            if (o) atomicAdd(&blkStat[1], o);
-            if (nh) atomicAdd(&blkStat[2], nh);
-            if (nt) atomicAdd(&blkStat[3], nt);
-            if (px) atomicAdd(&blkStat[4], px);
-        }
-        __syncthreads();
-        if (tid < 5 && blkStat[tid] != 0u) {
-            const int slotOf[5] = {0, 1, 4, 5, 6};
-            atomicAdd(&A.counters[(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE + slotOf[tid]], (unsigned long long)blkStat[tid]);
-        }
-    }
-}
-
-// Assigns pixels to the groups of a pass (tile-major order, row-major inside a 16x16 tile, main.cpp:132-138) and
-// seeds their generators (the build's per-pixel state, replacing random.h:15-17).
-__global__ void init_groups_kernel(WfArgs A)
-{
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= A.groupCount) return;
-    const uint32_t tile = A.p.tileSize, tile2 = tile * tile;
-    const uint32_t tl = g / tile2, pix = g - tl * tile2; // tl-th tile of this pipeline
-    const uint32_t tq = A.workBase / tile2 + tl * A.partCount + A.partIndex;
-    uint32_t gt;
-    bool ok = true;
-    if (A.fullWidth) {
-        gt = A.firstOwned + tq * A.p.nranks;
-    } else {
-        uint32_t qx = tq % A.rtnx, qy = tq / A.rtnx;
-        gt = (A.rty0 + qy) * A.tilesXImage + (A.rtx0 + qx);
-        ok = (gt % A.p.nranks) == A.p.rank;
-    }
-    uint32_t tx = gt % A.tilesXImage, ty = gt / A.tilesXImage;
-    uint32_t x = tx * tile + pix % tile, y = ty * tile + pix / tile;
-    if (x < A.x0 || x > A.x1 || y < A.y0 || y > A.y1) ok = false;
-    A.gPixel[g] = ok ? (x | (y << 16)) : 0xffffffffu;
-    A.gRng[g] = ok ? pixel_seed(x, y, A.cam.width, A.p.seed) : 0u;
-    A.gInfo[g] = (uint32_t)PH_START << 20;
-    A.gColor[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-}
-
-// Rays of one (sharded) queue.  An entry names the owner slot; the ray itself is rebuilt from the slot's state exactly as
-// the reference builds it (camera.cpp:64-66; path_tracer.cpp:209-211 / 236-238; :269-273).  Results go to the owner.
-template <int MODE>
-struct QueueSrc {
-    const uint32_t* qe;
-    uint32_t shardCount[PRT_QSHARDS];
-    uint32_t shardCap;
-    uint32_t n;
-    uint32_t* cur;
-    const float4* S0;
-    const float4* S2;
-    const float4* S5; // per-slot light direction (environment light) or NULL (the scene's directional light)
-    float4* hitA;
-    uint2* hitB;
-    uint32_t* occl;
-    Vec3 camPos, lightDir;
-    float kFar;
-    uint32_t owner; // of the lane's current ray
-    __device__ __forceinline__ uint32_t count() const { return n; }
-    __device__ __forceinline__ uint32_t* cursor() const { return cur; }
-    __device__ __forceinline__ void load(uint32_t i, Vec3& org, Vec3& dir, float& maxT, uint32_t& rev)
-    {
-        // virtual index -> (shard, offset)
-        uint32_t v = i, base = 0;
-#pragma unroll
-        for (int k = 0; k < PRT_QSHARDS - 1; k++) {
-            bool next = v >= shardCount[k];
-            v -= next ? shardCount[k] : 0u;
-            base += next ? shardCap : 0u;
-            if (!next) break;
-        }
-        const uint32_t bits = __builtin_nontemporal_load(&qe[base + v]);
-        owner = bits & 0x3ffffffu;
-        rev = (bits >> 26) & 7u;
-        if (MODE == PRT_MODE_PACKET) {
-            float4 s2 = nt_load4(&S2[owner]);
-            org = camPos;
-            dir = mk3(s2.x, s2.y, s2.z);
-            maxT = 100000.0f; // camera.cpp:64
-        } else if (MODE == PRT_MODE_SINGLE) {
-            float4 s0 = nt_load4(&S0[owner]), s2 = nt_load4(&S2[owner]);
-            org = mk3(s0.x, s0.y, s0.z);
-            dir = mk3(s2.x, s2.y, s2.z);
-            maxT = kFar; // path_tracer.cpp:270
-        } else {
-            float4 s0 = nt_load4(&S0[owner]);
-            Vec3 L = mk3(0.0f, 0.0f, 0.0f);
-            if ((bits >> 29) & 1u) {
-                if (S5) {
-                    float4 l5 = nt_load4(&S5[owner]);
-                    L = mk3(l5.x, l5.y, l5.z);
-                } else {
-                    L = lightDir;
-                }
-            }
-            org = add3(mk3(s0.x, s0.y, s0.z), scale3(kFar, L)); // path_tracer.cpp:210, 237
-            dir = mk3(-L.x, -L.y, -L.z);
-            maxT = kFar - 0.0008f; // :209, 236
-        }
-    }
-    __device__ __forceinline__ void store_hit(uint32_t, const DevHit& h) const
-    {
-        nt_store4(&hitA[owner], make_float4(h.t, h.i, h.j, h.k));
-        hitB[owner] = make_uint2(h.primId, h.meshId);
-    }
-    __device__ __forceinline__ void store_occ(uint32_t, bool occ) const { occl[owner] = occ ? 1u : 0u; }
-};
-
-// Persistent lanes over one ray queue.  MODE = the queue id = the traversal mode.
-// Waves per SIMD the trace kernels are compiled for.  Without a bound the compiler takes 112 SGPRs, which caps a SIMD at 6 waves
-// (800 SGPRs per SIMD, MI355X_MICROARCH.md "Occupancy API"); 7 gives 94 SGPRs / 72 VGPRs with no spills and the best frame time
-// (C3: unbounded 533 ms, 8: 521 with 9 SGPR spills, 7: 514, 6 and 5: 535).
-#ifndef PRT_TRACE_WAVES
-#define PRT_TRACE_WAVES 7
-#endif
-template <int MODE, bool COUNT>
-#if PRT_TRACE_WAVES
-__global__ __launch_bounds__(PRT_BLOCK, PRT_TRACE_WAVES) void trace_kernel(WfArgs A)
-#else
-__global__ __launch_bounds__(PRT_BLOCK) void trace_kernel(WfArgs A)
-#endif
-{
-    // the packet traversal stacks (reference, entry distance) pairs: half as many entries in the same 16 KB, so that its
-    // blocks do not crowd the other kernels' out of the CU's LDS
-    constexpr int NLDS = (MODE == PRT_MODE_PACKET) ? PRT_STACK_LDS_PACKET : PRT_STACK_LDS;
-    __shared__ uint32_t ldsRef[NLDS * PRT_BLOCK];
-    __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
-    const uint32_t tid = threadIdx.x;
-    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
-    QueueSrc<MODE> src;
-    src.qe = A.qE[MODE];
-    src.n = 0;
-#pragma unroll
-    for (int k = 0; k < PRT_QSHARDS; k++) {
-        src.shardCount[k] = A.qWork[4 + MODE * PRT_QSHARDS + k];
-        src.n += src.shardCount[k];
-    }
-    src.shardCap = A.shardCap;
-    src.cur = &A.qWork[MODE];
-    src.S0 = A.S0;
-    src.S2 = A.S2;
-    src.S5 = A.sc.hasEnv ? A.S5 : nullptr;
-    src.camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
-    src.lightDir = mk3(A.sc.lightDir[0], A.sc.lightDir[1], A.sc.lightDir[2]);
-    src.kFar = 2.0f * A.sc.radius; // path_tracer.cpp:192
-    src.hitA = A.hitA;
-    src.hitB = A.hitB;
-    src.occl = A.occl;
-    src.owner = 0;
-    Traffic tr{0, 0, 0, 0};
-    uint32_t overflow = 0;
-    trace_loop<MODE, COUNT>(A.sc, src, st, tr, overflow);
-    unsigned long long* C = A.counters;
-#ifdef PRT_PROFILE
-    if ((tid & 63u) == 0) {
-        atomicAdd(&C[16 + MODE * 3], tr.nBox);
-        atomicAdd(&C[17 + MODE * 3], tr.nTri);
-        atomicAdd(&C[18 + MODE * 3], (unsigned long long)tr.nTap);
-    }
-#endif
-    if (COUNT) {
-        // 64-bit per-wave sums (a persistent lane can count more than 2^32 box tests)
-        unsigned long long b = tr.nBox, t = tr.nTri, p = tr.nTap;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            b += (unsigned long long)__shfl_xor((long long)b, o, 64);
-            t += (unsigned long long)__shfl_xor((long long)t, o, 64);
-            p += (unsigned long long)__shfl_xor((long long)p, o, 64);
-        }
-        if ((tid & 63u) == 0) {
-            if (b) atomicAdd(&C[2], b);
-            if (t) atomicAdd(&C[3], t);
-            if (p) atomicAdd(&C[5], p);
-        }
-    }
-    if (overflow) atomicAdd(&C[7], 1ull);
-}
 
 #include "prt_frame.h"
 
@@ -1028,42 +393,6 @@ static int upload_vec(prt_hip_ctx* c, const std::vector<T>& v, const T** out)
     return PRT_HIP_OK;
 }
 
-// One pipeline of a pass: its groups, queues and streams.
-struct PartRun {
-    WfArgs A;
-    uint32_t shadeBlocks = 0;
-    hipStream_t main = nullptr, side[PRT_SIDE_STREAMS] = {};
-    hipEvent_t fork = nullptr, join[PRT_SIDE_STREAMS] = {};
-    int index = 0;
-};
-
-// One iteration of one pipeline.  The four trace kernels of an iteration are independent of each other: the scatter kernel
-// (the longest) runs on the main stream, the other three on the side stream beside it, so that the tail of one persistent
-// grid is filled by the next (each kernel has its own stack-spill area); the next shade kernel waits for all four.  The
-// other pipeline's kernels fill what this one leaves idle -- above all the time its shade kernel would hold the GPU alone.
-template <bool COUNT>
-static void wf_iteration(const PartRun& P, uint32_t traceBlocks)
-{
-    const WfArgs& A = P.A;
-    (void)hipMemsetAsync(A.qWork, 0, (4 + Q_COUNT * PRT_QSHARDS) * sizeof(uint32_t), P.main); // claim cursors + shard counts
-    if (A.sc.hasEnv) hipLaunchKernelGGL((shade_kernel<COUNT, true>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
-    else hipLaunchKernelGGL((shade_kernel<COUNT, false>), dim3(P.shadeBlocks), dim3(PRT_BLOCK), 0, P.main, A);
-    (void)hipEventRecord(P.fork, P.main);
-    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET);
-    WfArgs B = A;
-    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipStreamWaitEvent(P.side[k], P.fork, 0);
-    // the three smaller kernels go round the side streams (1: one after the other, 3: each on its own)
-    B.spill = A.spill + 1 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_PACKET, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[0 % PRT_SIDE_STREAMS], B);
-    B.spill = A.spill + 2 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_PRIMARY, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[1 % PRT_SIDE_STREAMS], B);
-    B.spill = A.spill + 3 * spillWords;
-    hipLaunchKernelGGL((trace_kernel<Q_OCC_SINGLE, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.side[2 % PRT_SIDE_STREAMS], B);
-    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipEventRecord(P.join[k], P.side[k]);
-    hipLaunchKernelGGL((trace_kernel<Q_SCATTER, COUNT>), dim3(traceBlocks), dim3(PRT_BLOCK), 0, P.main, A);
-    for (int k = 0; k < PRT_SIDE_STREAMS; k++) (void)hipStreamWaitEvent(P.main, P.join[k], 0);
-}
-
 extern "C" {
 
 const char* prt_hip_last_error(void) { return g_err.c_str(); }
@@ -1082,23 +411,17 @@ static int create_resources(prt_hip_ctx* c)
     c->computeUnits = prop.multiProcessorCount;
     c->name = prop.name[0] ? prop.name : prop.gcnArchName;
     HIP_TRY(hipStreamCreate(&c->stream));
-    for (int k = 0; k < PRT_PARTS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evFork[k], hipEventDisableTiming));
-    for (int k = 0; k < PRT_PARTS * PRT_SIDE_STREAMS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming));
-    for (int k = 0; k < PRT_PARTS; k++) HIP_TRY(hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
-    for (int k = 0; k < (1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1; k++) HIP_TRY(hipStreamCreate(&c->aux[k]));
-    HIP_TRY(hipMalloc(&c->work, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->work, PRT_WORK_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     return PRT_HIP_OK;
 }
 
-// The library runs four streams side by side.  A host process that owns more streams of its own (RCCL, a framework) should
-// raise the HIP runtime's default of four hardware queues BEFORE its first HIP call (GPU_MAX_HW_QUEUES); the
-// library does not touch the process environment.
+// The library touches neither the process environment nor the HIP runtime's configuration: a render is one kernel on one
+// stream of the context.
 int prt_hip_create(int device, prt_hip_ctx** out)
 {
     if (!out) return fail(PRT_HIP_EINVAL, "out is NULL");
@@ -1144,15 +467,6 @@ void prt_hip_destroy(prt_hip_ctx* c)
         if (c->evT0[k]) (void)hipEventDestroy(c->evT0[k]);
         if (c->evT1[k]) (void)hipEventDestroy(c->evT1[k]);
     }
-    for (int k = 0; k < (1 + PRT_SIDE_STREAMS) * PRT_PARTS - 1; k++)
-        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
-    for (int k = 0; k < PRT_PARTS; k++)
-        if (c->evFork[k]) (void)hipEventDestroy(c->evFork[k]);
-    for (int k = 0; k < PRT_PARTS * PRT_SIDE_STREAMS; k++)
-        if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
-    if (c->evStart) (void)hipEventDestroy(c->evStart);
-    for (int k = 0; k < PRT_PARTS; k++)
-        if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]);
     if (c->evIn) (void)hipEventDestroy(c->evIn);
     if (c->evOut) (void)hipEventDestroy(c->evOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1406,73 +720,15 @@ int prt_hip_set_camera(prt_hip_ctx* c, const prt_camera_desc* cam)
     return PRT_HIP_OK;
 }
 
+// Per-thread spill columns of the traversal stacks (entries beyond those kept in LDS): [entry][thread], two words per entry.
 static int ensure_launch_resources(prt_hip_ctx* c, uint32_t blocks)
 {
     uint32_t threads = blocks * PRT_BLOCK;
     if (threads > c->spillThreads) {
         if (c->spill) (void)hipFree(c->spill);
         c->spill = nullptr;
-        // one area per concurrently running trace kernel: four per pipeline
-        HIP_TRY(hipMalloc(&c->spill, 4 * PRT_PARTS * (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->spill, (size_t)threads * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET) * sizeof(uint32_t)));
         c->spillThreads = threads;
-    }
-    return PRT_HIP_OK;
-}
-
-static int persistent_blocks(prt_hip_ctx* c)
-{
-    if (c->blocksPerCU == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<Q_SCATTER, false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 2;
-        // Up to eight trace kernels are in flight (two pipelines x four queues) and a CU holds 8 blocks of 256 threads: 4 per
-        // kernel and CU leaves room for the other pipeline's kernels (measured on C3: 1: 933 ms, 2: 627, 3: 594, 4: 588,
-        // 5: 599, 6: 608, 8: 631)
-        c->blocksPerCU = std::min(nb, PRT_TRACE_BPC);
-    }
-    return c->computeUnits * c->blocksPerCU;
-}
-
-// Carves the wavefront state of the pipelines of a pass (groups[k] pixel groups each) out of one allocation.
-static int wf_layout(prt_hip_ctx* c, const uint32_t* groups, int parts, bool env, WfArgs* A)
-{
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    auto entries = [](size_t slots) { return slots + (size_t)PRT_QSHARDS * PRT_BLOCK + PRT_BLOCK; };
-    size_t need = 0;
-    for (int k = 0; k < parts; k++) {
-        const size_t g = groups[k], slots = g * 8;
-        need += 3 * al(g * sizeof(uint32_t)) + al(g * sizeof(float4));
-        need += (env ? 7 : 5) * al(slots * sizeof(float4));                                            // S0..S4 (S5, S6)
-        need += al(slots * sizeof(float4)) + al(slots * sizeof(uint2)) + al(slots * sizeof(uint32_t)); // hits, occlusion
-        need += Q_COUNT * al(entries(slots) * sizeof(uint32_t));
-    }
-    if (need > c->wfBytes) {
-        if (c->wfBuffer) (void)hipFree(c->wfBuffer);
-    if (c->frameArgs) (void)hipFree(c->frameArgs);
-    prt_gather_release(c);
-        c->wfBuffer = nullptr;
-        c->wfBytes = 0;
-        HIP_TRY(hipMalloc(&c->wfBuffer, need));
-        c->wfBytes = need;
-    }
-    char* p = (char*)c->wfBuffer;
-    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return r; };
-    for (int k = 0; k < parts; k++) {
-        const size_t g = groups[k], slots = g * 8;
-        A[k].gRng = (uint32_t*)take(g * sizeof(uint32_t));
-        A[k].gInfo = (uint32_t*)take(g * sizeof(uint32_t));
-        A[k].gPixel = (uint32_t*)take(g * sizeof(uint32_t));
-        A[k].gColor = (float4*)take(g * sizeof(float4));
-        A[k].S0 = (float4*)take(slots * sizeof(float4));
-        A[k].S1 = (float4*)take(slots * sizeof(float4));
-        A[k].S2 = (float4*)take(slots * sizeof(float4));
-        A[k].S3 = (float4*)take(slots * sizeof(float4));
-        A[k].S4 = (float4*)take(slots * sizeof(float4));
-        A[k].S5 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
-        A[k].S6 = env ? (float4*)take(slots * sizeof(float4)) : nullptr;
-        A[k].hitA = (float4*)take(slots * sizeof(float4));
-        A[k].hitB = (uint2*)take(slots * sizeof(uint2));
-        A[k].occl = (uint32_t*)take(slots * sizeof(uint32_t));
-        for (int q = 0; q < Q_COUNT; q++) A[k].qE[q] = (uint32_t*)take(entries(slots) * sizeof(uint32_t));
     }
     return PRT_HIP_OK;
 }
@@ -1525,18 +781,11 @@ static int frame_layout(prt_hip_ctx* c, uint32_t blocks, bool env, FrameArgs& A)
     return PRT_HIP_OK;
 }
 
-static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalWork, hipStream_t s)
+static int render_frame_kernel(prt_hip_ctx* c, FrameArgs& A, uint64_t totalWork, hipStream_t s)
 {
-    const prt_render_params* p = &W0.p;
-    FrameArgs A{};
-    A.sc = W0.sc; A.cam = W0.cam; A.p = W0.p;
-    A.x0 = W0.x0; A.y0 = W0.y0; A.x1 = W0.x1; A.y1 = W0.y1;
-    A.tilesXImage = W0.tilesXImage;
-    A.rtx0 = W0.rtx0; A.rty0 = W0.rty0; A.rtnx = W0.rtnx; A.rtny = W0.rtny;
-    A.fullWidth = W0.fullWidth; A.firstOwned = W0.firstOwned;
+    const prt_render_params* p = &A.p;
     A.totalWork = (uint32_t)totalWork;
     A.totalChunks = (uint32_t)((totalWork + PRT_CHUNK - 1) / PRT_CHUNK);
-    A.rgb = W0.rgb;
     A.counters = c->counters;
     A.ctrl = c->work;
     const uint32_t resident = (uint32_t)frame_blocks(c);
@@ -1546,12 +795,12 @@ static int render_frame_kernel(prt_hip_ctx* c, const WfArgs& W0, uint64_t totalW
     A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (A.totalChunks + blocks - 1) / blocks));
     A.spreadRows = (A.totalChunks < (uint64_t)blocks * PRT_POOL_CHUNKS * 2 && totalWork % PRT_CHUNK == 0) ? 1u : 0u;
     if (const char* e = getenv("PRT_SPREAD")) A.spreadRows = atoi(e) && totalWork % PRT_CHUNK == 0;
-    int rc = ensure_launch_resources(c, std::max<uint32_t>(resident, (uint32_t)persistent_blocks(c)));
+    int rc = ensure_launch_resources(c, resident);
     if (rc) return rc;
     A.spill = c->spill;
     A.spillStride = c->spillThreads;
     if ((rc = frame_layout(c, resident, c->sc.hasEnv != 0, A))) return rc;
-    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t), s));
     if (A.totalChunks == 0) return PRT_HIP_OK;
     const FrameArgs& dA = A;
     const bool env = c->sc.hasEnv != 0;
@@ -1589,10 +838,8 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     if (p->samples == 0 || p->tileSize == 0 || p->nranks == 0 || p->rank >= p->nranks) return fail(PRT_HIP_EINVAL, "bad render params");
     if (W > 65535 || H > 65535 || p->samples / 8 > 255 || p->maxDepth > 255) return fail(PRT_HIP_EINVAL, "image, sample count or depth too large");
     HIP_TRY(hipSetDevice(c->device));
-    // The pipeline always runs on the context's own streams (the main one and the three that carry the concurrent trace
-    // kernels; a foreign stream can share a hardware queue with one of those and serialise them -- 8 % on C3).  A caller's
-    // stream is ordered around it with two events: work queued on it before this call is finished before the first kernel
-    // starts, and whatever the caller queues next waits for the last one.
+    // The frame kernel runs on the context's own stream; a caller's stream is ordered around it with two events: work
+    // queued on it before this call is finished before the kernel starts, and whatever the caller queues next waits for it.
     hipStream_t s = c->stream;
     hipStream_t caller = (stream && (hipStream_t)stream != c->stream) ? (hipStream_t)stream : nullptr;
     if (caller) {
@@ -1609,12 +856,13 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         }
         d_rgb = c->fb;
     }
-    WfArgs A{};
+    FrameArgs A{};
     A.sc = c->sc;
     A.cam = c->cam;
     A.p = *p;
     A.x0 = x0; A.y0 = y0; A.x1 = x1; A.y1 = y1;
     const uint32_t T = p->tileSize;
+    if ((uint64_t)T * T > (1u << 20)) return fail(PRT_HIP_EINVAL, "tile too large");
     A.tilesXImage = (W + T - 1) / T;
     A.rtx0 = x0 / T; A.rty0 = y0 / T;
     A.rtnx = x1 / T - A.rtx0 + 1;
@@ -1634,76 +882,6 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     }
     if (totalWork > 0xffffffffull) return fail(PRT_HIP_EINVAL, "rectangle too large");
     A.rgb = d_rgb;
-    A.qWork = c->work;
-    A.counters = c->counters;
-    static const bool useWavefrontPipeline = getenv("PRT_SCHED") && !strcmp(getenv("PRT_SCHED"), "wave"); // A/B during development
-    if (!useWavefrontPipeline) {
-        if (p->tileSize * p->tileSize > (1u << 20)) return fail(PRT_HIP_EINVAL, "tile too large");
-        HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
-        if (c->ringUsed == PRT_TIMING_RING) fold_timing(c);
-        if (!c->evT0[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT0[c->ringUsed]));
-        if (!c->evT1[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT1[c->ringUsed]));
-        hipEvent_t e0 = c->evT0[c->ringUsed], e1 = c->evT1[c->ringUsed];
-        c->ringUsed++;
-        HIP_TRY(hipEventRecord(e0, s));
-        int frc = render_frame_kernel(c, A, totalWork, s);
-        if (frc) return frc;
-        hipError_t fle = hipGetLastError();
-        if (fle != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("frame_kernel launch: ") + hipGetErrorString(fle));
-        HIP_TRY(hipEventRecord(e1, s));
-        c->lastRank = p->rank;
-        c->lastNranks = p->nranks;
-        c->lastTile = p->tileSize;
-        c->lastTarget = d_rgb;
-        if (caller) {
-            HIP_TRY(hipEventRecord(c->evOut, s));
-            HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
-        }
-        c->timed = true;
-        c->frameLaunched = true;
-        return PRT_HIP_OK;
-    }
-    const uint32_t traceBlocks = (uint32_t)persistent_blocks(c);
-    int rc = ensure_launch_resources(c, traceBlocks);
-    if (rc) return rc;
-    A.spillStride = c->spillThreads;
-    // A pass holds at most 2^26 slot references (the 26-bit owner field of a queued ray) per pipeline and whole tiles.
-    const uint32_t tile2 = T * T;
-    if (tile2 > (1u << 20)) return fail(PRT_HIP_EINVAL, "tile too large");
-    const uint64_t totalTiles = totalWork / tile2;
-    const uint64_t kMaxGroupsPerPass = 4u << 20;
-    const uint64_t passTiles = std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(totalTiles, 1), kMaxGroupsPerPass / tile2));
-    // two pipelines as soon as each gets a few tiles; tiny launches keep one
-    const int parts = (std::min<uint64_t>(passTiles, totalTiles) >= 4 * PRT_PARTS) ? PRT_PARTS : 1;
-    PartRun P[PRT_PARTS];
-    const size_t spillWords = (size_t)A.spillStride * 2 * (PRT_STACK_MAX - PRT_STACK_LDS_PACKET);
-    {
-        uint32_t maxGroups[PRT_PARTS];
-        WfArgs L[PRT_PARTS];
-        for (int k = 0; k < parts; k++) maxGroups[k] = (uint32_t)(((passTiles - k + parts - 1) / parts) * tile2);
-        if ((rc = wf_layout(c, maxGroups, parts, c->sc.hasEnv != 0, L))) return rc;
-        for (int k = 0; k < parts; k++) {
-            P[k].A = A;
-            P[k].A.gRng = L[k].gRng; P[k].A.gInfo = L[k].gInfo; P[k].A.gPixel = L[k].gPixel; P[k].A.gColor = L[k].gColor;
-            P[k].A.S0 = L[k].S0; P[k].A.S1 = L[k].S1; P[k].A.S2 = L[k].S2; P[k].A.S3 = L[k].S3; P[k].A.S4 = L[k].S4;
-            P[k].A.S5 = L[k].S5; P[k].A.S6 = L[k].S6;
-            P[k].A.hitA = L[k].hitA; P[k].A.hitB = L[k].hitB; P[k].A.occl = L[k].occl;
-            for (int q = 0; q < Q_COUNT; q++) P[k].A.qE[q] = L[k].qE[q];
-            P[k].A.qWork = c->work + (size_t)k * PRT_WORK_WORDS;
-            P[k].A.spill = c->spill + (size_t)k * 4 * spillWords;
-            P[k].A.partIndex = (uint32_t)k;
-            P[k].A.partCount = (uint32_t)parts;
-            // streams of pipeline k: aux[k*(1+S) - 1] (main; pipeline 0 uses the context's stream) and the S after it
-            P[k].main = (k == 0) ? s : c->aux[k * (1 + PRT_SIDE_STREAMS) - 1];
-            for (int j = 0; j < PRT_SIDE_STREAMS; j++) {
-                P[k].side[j] = c->aux[k * (1 + PRT_SIDE_STREAMS) + j];
-                P[k].join[j] = c->evJoin[k * PRT_SIDE_STREAMS + j];
-            }
-            P[k].fork = c->evFork[k];
-            P[k].index = k;
-        }
-    }
-
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
     if (c->ringUsed == PRT_TIMING_RING) fold_timing(c);
     if (!c->evT0[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT0[c->ringUsed]));
@@ -1711,39 +889,10 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
     hipEvent_t ev0 = c->evT0[c->ringUsed], ev1 = c->evT1[c->ringUsed];
     c->ringUsed++;
     HIP_TRY(hipEventRecord(ev0, s));
-    const uint32_t iterations = (p->samples / 8) * (1 + p->maxDepth) + 1;
-    for (uint64_t baseTile = 0; baseTile < totalTiles; baseTile += passTiles) {
-        const uint64_t tilesNow = std::min<uint64_t>(passTiles, totalTiles - baseTile);
-        // pipeline 1 starts after everything queued on the main stream so far (the previous pass included)
-        if (parts > 1) {
-            HIP_TRY(hipEventRecord(c->evStart, s));
-            for (int k = 1; k < parts; k++) HIP_TRY(hipStreamWaitEvent(P[k].main, c->evStart, 0));
-        }
-        int live = 0;
-        for (int k = 0; k < parts; k++) {
-            const uint64_t tilesOfPart = (tilesNow > (uint64_t)k) ? (tilesNow - k + parts - 1) / parts : 0;
-            P[k].A.workBase = (uint32_t)(baseTile * tile2);
-            P[k].A.groupCount = (uint32_t)(tilesOfPart * tile2);
-            P[k].shadeBlocks = (uint32_t)(((uint64_t)P[k].A.groupCount * 8 + PRT_BLOCK - 1) / PRT_BLOCK);
-            P[k].A.shardCap = ((P[k].shadeBlocks + PRT_QSHARDS - 1) / PRT_QSHARDS) * PRT_BLOCK;
-            if (P[k].A.groupCount == 0) continue;
-            live = k + 1;
-            hipLaunchKernelGGL(init_groups_kernel, dim3((P[k].A.groupCount + 255) / 256), dim3(256), 0, P[k].main, P[k].A);
-        }
-        for (uint32_t it = 0; it < iterations; it++) {
-            for (int k = 0; k < live; k++) {
-                if (P[k].A.groupCount == 0) continue;
-                if (p->countTraffic) wf_iteration<true>(P[k], traceBlocks);
-                else wf_iteration<false>(P[k], traceBlocks);
-            }
-        }
-        for (int k = 1; k < parts; k++) {
-            HIP_TRY(hipEventRecord(c->evDone[k], P[k].main));
-            HIP_TRY(hipStreamWaitEvent(s, c->evDone[k], 0));
-        }
-    }
+    int rc = render_frame_kernel(c, A, totalWork, s);
+    if (rc) return rc;
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("wavefront launch: ") + hipGetErrorString(le));
+    if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("frame_kernel launch: ") + hipGetErrorString(le));
     HIP_TRY(hipEventRecord(ev1, s));
     c->lastRank = p->rank;
     c->lastNranks = p->nranks;
@@ -1754,6 +903,7 @@ int prt_hip_render(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1, uint32
         HIP_TRY(hipStreamWaitEvent(caller, c->evOut, 0));
     }
     c->timed = true;
+    c->frameLaunched = true;
     return PRT_HIP_OK;
 }
 
@@ -1785,11 +935,12 @@ int prt_hip_render_gbuffer(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1
     const uint32_t rw = x1 - x0 + 1, rh = y1 - y0 + 1;
     if ((uint64_t)rw * rh > 0xffffffffull) return fail(PRT_HIP_EINVAL, "rectangle too large");
     const uint32_t want = (uint32_t)(((uint64_t)rw * rh + PRT_BLOCK - 1) / PRT_BLOCK);
-    const uint32_t blocks = std::min<uint32_t>(want, (uint32_t)persistent_blocks(c));
-    int rc = ensure_launch_resources(c, (uint32_t)persistent_blocks(c));
+    const uint32_t resident = (uint32_t)(c->computeUnits * 4); // persistent lanes: 4 blocks of 256 per CU
+    const uint32_t blocks = std::min<uint32_t>(want, resident);
+    int rc = ensure_launch_resources(c, resident);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), s));
-    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t), s));
     GbufArgs A{c->sc, c->cam, x0, y0, rw, rh, type, seed, exposure, d_rgb, c->work, c->spill, c->spillThreads, c->counters};
     hipLaunchKernelGGL(gbuffer_kernel, dim3(blocks), dim3(PRT_BLOCK), 0, s, A);
     hipError_t le = hipGetLastError();
@@ -1831,15 +982,6 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
         for (int sh = 0; sh < PRT_STAT_SHARDS; sh++)
             for (int k = 0; k < PRT_STAT_STRIDE; k++) h[k] += all[(size_t)sh * PRT_STAT_STRIDE + k];
     }
-#ifdef PRT_STAMP
-    {
-        const char* names[13] = {"header", "consume-rest", "bounce-rest", "end+camera", "emit-writes", "store", "state-loads", "hit+surface",
-                                 "bump", "mats+rng", "diffuse", "emit-sync1", "emit-sync2"};
-        fprintf(stderr, "shade stamps (avg cycles per wave, %llu waves):", h[23]);
-        for (int k = 0; k < 13; k++) fprintf(stderr, " %s %.0f", names[k], (double)h[8 + k] / (double)(h[23] ? h[23] : 1));
-        fprintf(stderr, "\n");
-    }
-#endif
     if (c->frameLaunched) {
         uint32_t ctrl[8 + 16 * 8] = {0};
         HIP_TRY(hipMemcpy(ctrl, c->work, sizeof(ctrl), hipMemcpyDeviceToHost));
@@ -1859,11 +1001,6 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     if (h[14])
         fprintf(stderr, "frame profile: waves %llu, per wave: shade %.1f%% (%.0f calls) trace %.1f%% (%.0f calls) idle/decide %.1f%% of %.2f Mcycles\n", h[14],
                 100.0 * h[8] / h[13], (double)h[11] / h[14], 100.0 * h[9] / h[13], (double)h[12] / h[14], 100.0 * h[10] / h[13], h[13] / 1e6 / h[14]);
-    if (!h[14] && h[16 + 3])
-        for (int m = 0; m < 4; m++)
-            fprintf(stderr, "  wavefront trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.0f kcycles per... total %.1f Gcycles in loops => %.0f cycles per turn\n", m,
-                    h[16 + 3 * m] / 1e6, (double)h[17 + 3 * m] / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1), 0.0, h[18 + 3 * m] * 1024.0 / 1e9,
-                    h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
     if (h[14]) {
         for (int m = 0; m < 4; m++)
             fprintf(stderr, "  trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.1f Gcycles in the loops => %.0f cycles per turn\n", m, h[16 + 3 * m] / 1e6,
@@ -1919,7 +1056,7 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     HIP_TRY(hipMemcpy(dorg.p, org, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ddir.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_PARTS * PRT_WORK_WORDS * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t), c->stream));
     RaysArgs A{c->sc, n, dorg.as<float>(), ddir.as<float>(), maxT, dh.as<prt_hit>(), c->work, c->spill, c->spillThreads, c->counters};
     blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
     if (mode == 0) hipLaunchKernelGGL(rays_kernel<PRT_MODE_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
