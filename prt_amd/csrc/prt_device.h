@@ -42,6 +42,7 @@
 // alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
 struct DevScene {
     const float4* wnodes;
+    const float4* hotNodes; // PRT_HOT_NODES records (4 x float4 each): copies of the records that PRT_REF_HOT references name
     const float4* tris;
     const float4* shade;
     const float4* bump;
@@ -400,6 +401,12 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
 //   internal: index of the child's own wide record (< 2^30)
 //   leaf:     PRT_REF_LEAF | firstTriangle << 4 | primCount      (primCount 1..8, firstTriangle < 2^27)
 #define PRT_REF_LEAF 0x80000000u
+// The records nearest to the roots (breadth-first, PRT_HOT_NODES of them) are visited by every ray.  References to them
+// carry PRT_REF_HOT | slot: a kernel that keeps a copy of those records in LDS (the frame kernel) reads them there with
+// ds_read_b128 instead of sending four more gathers down the texture-address path, the busiest unit of these kernels
+// (profiles/: TA busy 76 % of the frame); other kernels read the same copy from DevScene::hotNodes.
+#define PRT_REF_HOT 0x40000000u
+#define PRT_HOT_NODES 64
 
 // Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper
 // ones in a per-thread global spill area.  `t` (the box entry distance) is only stored by the packet traversal.
@@ -407,12 +414,14 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
 // texture path the node and triangle fetches already saturate
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) prt_f4 lds_f4;
 template <int NLDS> // stack entries kept in LDS; deeper ones spill (NLDS a power of two)
 struct StackT {
     lds_u32* ldsRef; // &refs[threadIdx.x]
     lds_f32* ldsT;   // &ts[threadIdx.x]
     uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
     uint32_t spillStride;
+    const lds_f4* hot; // the block's LDS copy of DevScene::hotNodes, or NULL
     __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
         if (e < NLDS) ldsRef[e * PRT_BLOCK] = ref;
@@ -451,14 +460,24 @@ struct WideNode {
     __device__ __forceinline__ Box box1() const { return Box{mk3(w2.x, w2.z, w1.z), mk3(w2.y, w2.w, w1.w)}; }
 };
 
-__device__ __forceinline__ void load_wide(const DevScene& sc, uint32_t idx, WideNode& w)
+template <class STK>
+__device__ __forceinline__ void load_wide(const DevScene& sc, const STK& st, uint32_t idx, WideNode& w)
 {
-    const float4* p = sc.wnodes + 4 * (size_t)idx;
     float4 w3;
-    w.w0 = gld4(p);
-    w.w1 = gld4(p + 1);
-    w.w2 = gld4(p + 2);
-    w3 = gld4(p + 3);
+    if (st.hot != nullptr && (idx & PRT_REF_HOT)) {
+        const lds_f4* h = st.hot + 4u * (idx & (PRT_HOT_NODES - 1u));
+        const prt_f4 a = h[0], b = h[1], c = h[2], d = h[3];
+        w.w0 = make_float4(a.x, a.y, a.z, a.w);
+        w.w1 = make_float4(b.x, b.y, b.z, b.w);
+        w.w2 = make_float4(c.x, c.y, c.z, c.w);
+        w3 = make_float4(d.x, d.y, d.z, d.w);
+    } else {
+        const float4* p = (idx & PRT_REF_HOT) ? sc.hotNodes + 4u * (idx & (PRT_HOT_NODES - 1u)) : sc.wnodes + 4 * (size_t)idx;
+        w.w0 = gld4(p);
+        w.w1 = gld4(p + 1);
+        w.w2 = gld4(p + 2);
+        w3 = gld4(p + 3);
+    }
     w.ref0 = asu(w3.x);
     w.ref1 = asu(w3.y);
     w.axis = asu(w3.z);
@@ -666,7 +685,7 @@ template <int MODE, bool COUNT, class STK>
 __device__ __forceinline__ void tracer_node(const DevScene& sc, Tracer& T, const STK& st, Traffic& tr, uint32_t& overflow)
 {
     WideNode w;
-    load_wide(sc, T.ref, w);
+    load_wide(sc, st, T.ref, w);
     if (T.sp + 2 >= PRT_STACK_MAX) { // bvh.cpp:552, 627
         overflow = 1;
         T.ref = PRT_REF_NONE;

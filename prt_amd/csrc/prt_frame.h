@@ -94,9 +94,10 @@ struct FrameArgs {
     uint32_t spillStride;
 };
 
-struct BlockState { // LDS, one per workgroup
+struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
     uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
+    float hot[PRT_HOT_NODES * 16]; // DevScene::hotNodes (16-byte aligned: read with ds_read_b128)
     uint32_t pending[PRT_POOL_GROUPS];
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
@@ -580,7 +581,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const uint32_t slotBase = blockIdx.x * PRT_POOL_SLOTS;
     const uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid),
-                          A.spillStride};
+                          A.spillStride, (const lds_f4*)&B->hot[0]};
     const DevScene& sc = A.sc;
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
@@ -852,6 +853,13 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
     const BlockLds B = block_lds();
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < PRT_POOL_GROUPS; i += PRT_BLOCK) B->pending[i] = PEND_DONE;
+    for (uint32_t i = tid; i < PRT_HOT_NODES * 4u; i += PRT_BLOCK) {
+        const float4 v = gld4(A.sc.hotNodes + i);
+        B->hot[4 * i] = v.x;
+        B->hot[4 * i + 1] = v.y;
+        B->hot[4 * i + 2] = v.z;
+        B->hot[4 * i + 3] = v.w;
+    }
     if (tid < PRT_POOL_CHUNKS) B->chunkLive[tid] = 0;
     if (tid < Q_COUNT) {
         B->qTail[tid] = 0;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
     __shared__ float ldsT[PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
     GbufSrc src{&A};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
     __shared__ uint32_t ldsRef[NLDS * PRT_BLOCK];
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride};
+    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
     ArraySrc src{&A, MODE};
     Traffic tr{0, 0, 0, 0};
     uint32_t overflow = 0;
@@ -635,6 +635,30 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             }
         }
     }
+    // The PRT_HOT_NODES records nearest to the roots, breadth first over the BVHs in order; references to them become
+    // PRT_REF_HOT | slot everywhere (parents' records, root references), and `hot` holds copies of the rewritten records.
+    std::vector<float4> hot((size_t)PRT_HOT_NODES * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    {
+        auto bitsOf = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        std::vector<uint32_t> order; // record indices, breadth first
+        for (uint32_t m = 0; m < sc.bvhCount; m++)
+            if (!(sc.rootRef[m] & PRT_REF_LEAF)) order.push_back(sc.rootRef[m]);
+        for (size_t head = 0; head < order.size() && order.size() < PRT_HOT_NODES; head++) {
+            const float4& refs = wnodes[(size_t)order[head] * 4 + 3];
+            for (uint32_t r : {bitsOf(refs.x), bitsOf(refs.y)})
+                if (!(r & PRT_REF_LEAF) && order.size() < PRT_HOT_NODES) order.push_back(r);
+        }
+        std::vector<uint32_t> slotOf(wnodes.size() / 4, 0xffffffffu);
+        for (size_t k = 0; k < order.size(); k++) slotOf[order[k]] = (uint32_t)k;
+        auto hotRef = [&](uint32_t r) { return (!(r & PRT_REF_LEAF) && slotOf[r] != 0xffffffffu) ? (PRT_REF_HOT | slotOf[r]) : r; };
+        for (size_t rec = 0; rec < wnodes.size() / 4; rec++) {
+            float4& refs = wnodes[rec * 4 + 3];
+            refs.x = ubits(hotRef(bitsOf(refs.x)));
+            refs.y = ubits(hotRef(bitsOf(refs.y)));
+        }
+        for (uint32_t m = 0; m < sc.bvhCount; m++) sc.rootRef[m] = hotRef(sc.rootRef[m]);
+        for (size_t k = 0; k < order.size(); k++) memcpy(&hot[k * 4], &wnodes[(size_t)order[k] * 4], 4 * sizeof(float4));
+    }
     sc.hasLight = s->hasDirectionalLight ? 1u : 0u;
     memcpy(sc.lightDir, s->lightDir, 12);
     memcpy(sc.lightIntensity, s->lightIntensity, 12);
@@ -698,6 +722,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         }
     if (mats.size() % PRT_MAT_STRIDE != 0) return fail(PRT_HIP_EINVAL, "internal: material table is not a whole number of records");
     if ((rc = upload_vec(c, wnodes, &sc.wnodes))) return rc;
+    if ((rc = upload_vec(c, hot, &sc.hotNodes))) return rc;
     if ((rc = upload_vec(c, tris, &sc.tris))) return rc;
     if ((rc = upload_vec(c, shade, &sc.shade))) return rc;
     if ((rc = upload_vec(c, bump, &sc.bump))) return rc;
