@@ -37,7 +37,8 @@ WORKLOADS = {
                           "1920x1080, 64 spp, depth 8"),
     "c2_bunny_standin": ("setup_bunny_standin", dict(tris=69451, seed=1), 1024, 1024, 64, 14,
                          "BASELINE config 2: Cornell box + bunny-class stand-in (69k tris) + directional light, 1024x1024, 64 spp"),
-    "c1_cornell_teapot": ("setup_cornell_box", dict(), 512, 512, 16, 4, "BASELINE config 1: Cornell box (teapot needs the reference's asset), 512x512, 16 spp, depth 4"),
+    "c1_cornell_teapot": ("setup_cornell_box", dict(teapot="fixture"), 512, 512, 16, 4,
+                          "BASELINE config 1: Cornell box + teapot (the reference's teapot.obj as vertex arrays, tests/golden/teapot_mesh.npz), 512x512, 16 spp, depth 4"),
     # the two 8-GPU configurations of BASELINE.json (parity-test cases; selectable, never the default)
     "c4_sanmiguel_standin": ("setup_atrium_standin", dict(tris=2500000, seed=4), 1920, 1080, 256, 14,
                              "BASELINE config 4: San-Miguel-class stand-in (2.5 M tris, alpha-masked foliage cards, bump map, directional light), "
@@ -55,20 +56,34 @@ def algorithmic_bytes(st):
     return 32 * st["nBox"] + 40 * st["nTri"] + 112 * st["nHit"] + 16 * st["nTap"] + 12 * st["nPx"]
 
 
-def pmc_traffic(workload, world):
-    """(bytes per frame, None, source) from the newest committed PMC summary of this workload; (None, None, None) otherwise."""
-    if world != 1:
-        return None, None, None
+def algorithmic_split(st):
+    """The algorithmic bytes by role of the frame kernel: the four traversals (32 B per box test, 40 B per triangle test, 16 B
+    per alpha-test tap) and the shade passes (112 B per surface fetch, 16 B per shading tap, 12 B per pixel)."""
+    names = ("trace primary packets", "trace scatter rays", "trace packet occlusion rays", "trace single occlusion rays")
+    out = {n: 32 * st["modeBox"][m] + 40 * st["modeTri"][m] + 16 * st["modeTap"][m] for m, n in enumerate(names)}
+    out["shade"] = 112 * st["nHit"] + 16 * (st["nTap"] - sum(st["modeTap"])) + 12 * st["nPx"]
+    return out
+
+
+def counter_evidence(workload, world, overridden):
+    """The committed counter summary of this workload (profiles/*_counters.json: separate rocprofv3 --pmc passes, one counter
+    block each, summarised by tools/pmc_evidence.py), or None.  It is only used when it was taken with the kernel sources this
+    process runs (source_sha16) on the workload's own size: the HBM-side bytes of a launch cannot be measured from inside
+    the process, and a stale file must not pass for a measurement."""
+    if world != 1 or overridden:
+        return None
     import glob
+    import prt_amd
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == workload:
-            best = (float(d["traffic_bytes_per_frame"]), None, "profiles/" + os.path.basename(f))
-    return best if best else (None, None, None)
+        if d.get("workload") == workload and d.get("source_sha16") == prt_amd.source_sha16():
+            d["file"] = "profiles/" + os.path.basename(f)
+            best = d
+    return best
 
 
 def host_cores():
@@ -183,6 +198,15 @@ def main():
         prt_amd.build()
     if use_dist:
         dist.barrier()
+    kw = dict(kw)
+    if kw.pop("teapot", None) == "fixture":  # C1's teapot: the committed vertex arrays of the reference's teapot.obj (main.cpp:28-50)
+        z = np.load(os.path.join(ROOT, "tests", "golden", "teapot_mesh.npz"))
+        mat = prt_amd.Material.make(diffuse=(0.9, 0.9, 0.9), reflection=prt_amd.Material.SPECULAR)
+        idx = np.ascontiguousarray(z["indices"], dtype=np.uint32).reshape(-1, 3)
+        teapot = prt_amd.Mesh.from_arrays(idx, z["positions"].astype(np.float32), np.zeros(len(idx), dtype=np.uint32),
+                                          np.frombuffer(bytes(mat), dtype=prt_amd.MATERIAL_DTYPE), texcoords=z["texcoords"])
+        teapot.transform(0.005, (-0.5, 0.0, 0.5))
+        kw["teapot_mesh"] = teapot
     scene, camera, exposure = getattr(prt_amd, setup)(W, H, **kw)
     tracer = prt_amd.PathTracer(device=local_rank, max_depth=depth, seed=args.seed)
     tracer.upload_scene(scene)
@@ -241,11 +265,9 @@ def main():
         ct = tracer.stats()
         B = algorithmic_bytes(ct)
         achieved = B / (kernel_ms * 1e-3) / 1e9
-        # HBM-side bytes of one launch: not measurable from inside the process; taken from the committed PMC passes of this
-        # same workload (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, guide corrections)
-        traffic_bytes, traffic_rate, traffic_src = pmc_traffic(args.workload, world)
-        if traffic_bytes is not None:
-            traffic_rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9
+        ev = counter_evidence(args.workload, world, bool(args.spp or args.width or args.height or args.max_depth))
+        traffic_bytes = ev["traffic_bytes_per_frame"] if ev else None
+        traffic_rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9 if ev else None
         value = rays_per_step * args.steps / dt / 1e6
         name, cus = tracer.device_info()
         out = {
@@ -257,14 +279,39 @@ def main():
                        "seed": args.seed, "rays_per_step": int(rays_per_step), "occlusion_rays_per_step": int(occl_per_step),
                        "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL send/recv image gather of {tracer.gather_payload_bytes()} B per rank" if world > 1
                        else "one GPU", "device": name, "compute_units": cus},
+            # `achieved` / `frac` are the contract's ALGORITHMIC figure (layout-independent bytes of the events the
+            # reference's algorithm performs, most of them served by L1/L2) -- not a claim that DRAM is busy.  What DRAM and the
+            # memory pipeline really do is beside it: `traffic` / `hbm_frac` (fabric-side counters) and `limiter` (from the same file).
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic_rate, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src, "kernel": "wavefront pipeline of one frame: shade_kernel + trace_kernel<0..3>, (spp/8)*(1+depth)+1 iterations", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": int(B),
-                         "events_per_launch": {k: ct[k] for k in ("nBox", "nTri", "nHit", "nTap", "nPx")}},
+                         "traffic": traffic_rate, "hbm_frac": (traffic_rate / HBM_PEAK_GBS) if traffic_rate else None,
+                         "traffic_bytes_per_launch": traffic_bytes, "traffic_source": ev["file"] if ev else None,
+                         "traffic_source_sha16": ev["source_sha16"] if ev else None, "source_sha16": prt_amd.source_sha16(),
+                         "limiter": ("vector-memory gather path and dependent L2 round trips, not DRAM bytes: texture-address units busy "
+                                     f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f} of the frame, waves waiting "
+                                     f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, "
+                                     f"L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit {ev['derived']['l2_hit_rate']:.2f}, "
+                                     f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction") if ev
+                         else "see profiles/ (no counter summary taken with these kernel sources)",
+                         "kernel": "frame_kernel: one persistent launch per frame (shade passes + four ray traversals as roles of its waves)",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(B),
+                         "events_per_launch": {k: ct[k] for k in ("nBox", "nTri", "nHit", "nTap", "nPx")},
+                         "algorithmic_bytes_by_role": algorithmic_split(ct)},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(scene, camera, exposure, spp, depth, args.seed, args.cpu_seconds)
+                cb = cpu_baseline(scene, camera, exposure, spp, depth, args.seed, args.cpu_seconds)
+                if cb.get("kind") == "reference" and depth != 14:
+                    # The compiled reference only knows its literal depth cap of 14 (path_tracer.cpp:124).  So that ONE pair of
+                    # figures is the same algorithm at the same cap, the GPU renders the whole frame once more at cap 14:
+                    tracer.max_depth = 14
+                    tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure)
+                    torch.cuda.synchronize()
+                    s14 = tracer.stats()
+                    tracer.max_depth = depth
+                    cb["same_cap"] = {"max_depth": 14, "gpu_value": s14["raysTraced"] / s14["kernelMs"] / 1e3, "cpu_value": cb["value"],
+                                      "gpu_over_cpu": s14["raysTraced"] / s14["kernelMs"] / 1e3 / cb["value"],
+                                      "note": "GPU: whole frame at depth cap 14; CPU: the compiled reference on the window of `sample`"}
+                out["cpu_baseline"] = cb
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

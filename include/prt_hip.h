@@ -124,6 +124,9 @@ typedef struct {
     uint64_t raysTraced;     /* path_tracer.cpp:62,219,242,276 */
     uint64_t occludedTraced; /* path_tracer.cpp:220,243 */
     uint64_t nBox, nTri, nHit, nTap, nPx;
+    /* the traversal events again, per traversal (0 primary packets, 1 scatter rays, 2 packet / 3 single occlusion rays); the taps
+     * here are the alpha tests inside leaves -- nTap minus their sum are the shading taps (countTraffic launches only) */
+    uint64_t modeBox[4], modeTri[4], modeTap[4];
     uint64_t stackOverflow;  /* lanes that needed more than 64 stack entries (must be 0) */
     double kernelMs;         /* HIP-event time of the last render's kernel (events on the launch stream) */
     double kernelMsSum;      /* sum over the render launches since the previous prt_hip_get_stats */

@@ -78,12 +78,16 @@ class RenderParams(C.Structure):
 
 
 class HipStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx",
-                                          "stackOverflow")] + [("kernelMs", C.c_double), ("kernelMsSum", C.c_double),
-                                                               ("kernelLaunches", C.c_uint64)]
+    _fields_ = ([(n, C.c_uint64) for n in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx")]
+                + [("modeBox", C.c_uint64 * 4), ("modeTri", C.c_uint64 * 4), ("modeTap", C.c_uint64 * 4), ("stackOverflow", C.c_uint64),
+                   ("kernelMs", C.c_double), ("kernelMsSum", C.c_double), ("kernelLaunches", C.c_uint64)])
 
     def as_dict(self):
-        return {n: (float(getattr(self, n)) if n.startswith("kernelMs") else int(getattr(self, n))) for n, _ in self._fields_}
+        out = {}
+        for n, t in self._fields_:
+            v = getattr(self, n)
+            out[n] = [int(x) for x in v] if n.startswith("mode") else (float(v) if n.startswith("kernelMs") else int(v))
+        return out
 
 
 class Hit(C.Structure):
@@ -123,6 +127,10 @@ def build(force=False):
     for gfx950 with hipcc, in tree."""
     _build.build_library(force=force, test_entry_points=True)
     return _build.build_library(force=force)
+
+
+def source_sha16():
+    return _build.source_sha16()
 
 
 def lib():

@@ -56,3 +56,14 @@ def build_library(force=False, verbose=False, test_entry_points=False):
     subprocess.check_call(cmd)
     os.replace(tmp, lib)
     return lib
+
+
+def source_sha16():
+    """First 16 hex digits of the SHA-256 over the kernel sources: profiles/*.json carry it, so that bench.py can tell whether
+    a committed counter summary was taken with the code it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(["prt_kernels.hip", "prt_gather.hip", "prt_frame.h", "prt_device.h", "prt_devmath.h", "prt_internal.h"]):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]

@@ -739,7 +739,23 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
     if (overflow) lds_st(&B->overflow, 1u);
-    if (COUNT) block_count_traffic(B, tr);
+    if (COUNT) {
+        block_count_traffic(B, tr);
+        // the same events per traversal mode (bench.py splits the algorithmic bytes by them): words 16 + 3 * MODE of the counters
+        unsigned long long b = tr.nBox, t = tr.nTri, p = tr.nTap;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            b += (unsigned long long)__shfl_xor((long long)b, o, 64);
+            t += (unsigned long long)__shfl_xor((long long)t, o, 64);
+            p += (unsigned long long)__shfl_xor((long long)p, o, 64);
+        }
+        if (lane == 0) {
+            unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+            if (b) atomicAdd(&C[16 + MODE * 3], b);
+            if (t) atomicAdd(&C[17 + MODE * 3], t);
+            if (p) atomicAdd(&C[18 + MODE * 3], p);
+        }
+    }
     __builtin_amdgcn_s_setprio(0);
 #ifdef PRT_PROFILE
     if (lane == 0) {

@@ -1041,6 +1041,15 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     st->nHit = h[4];
     st->nTap = h[5];
     st->nPx = h[6];
+    for (int m = 0; m < 4; m++) {
+#ifdef PRT_PROFILE
+        st->modeBox[m] = st->modeTri[m] = st->modeTap[m] = 0; // the words carry the profile build's loop statistics
+#else
+        st->modeBox[m] = h[16 + 3 * m];
+        st->modeTri[m] = h[17 + 3 * m];
+        st->modeTap[m] = h[18 + 3 * m];
+#endif
+    }
     st->stackOverflow = h[7];
     fold_timing(c);
     st->kernelMs = c->accLaunches ? c->lastMs : 0.0;
