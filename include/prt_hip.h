@@ -152,6 +152,14 @@ int prt_hip_device_info(prt_hip_ctx* ctx, char* name, size_t cap, int* computeUn
 int prt_hip_upload_scene(prt_hip_ctx* ctx, const prt_scene_desc* scene);
 int prt_hip_set_camera(prt_hip_ctx* ctx, const prt_camera_desc* camera);
 
+/* ---- Bvh::build on the GPU: the reference's binned-SAH build (bvh.cpp:31-171) and depth-first linearisation
+ * (bvh.cpp:230-299) level by level on the device, producing the IDENTICAL node array (prt_bvh_node = LinearBvhNode),
+ * leaf order and primRemapping that Bvh::build produces on the host -- a mesh descriptor built from them is interchangeable
+ * with one from the host builder.  Host pointers: indices 3 * primCount, positions 3 * vertexCount; nodes_out has room for
+ * 2 * primCount nodes, primRemapping_out for primCount entries; buildMs (may be NULL) = device time of the build. ---- */
+int prt_hip_build_bvh(prt_hip_ctx* ctx, uint32_t primCount, const uint32_t* indices, uint32_t vertexCount, const float* positions,
+                      prt_bvh_node* nodes_out, uint32_t* nodeCount_out, uint32_t* primRemapping_out, double* buildMs);
+
 /* ---- the hot path: replaces PathTracer::TraceBlock (path_tracer.cpp:17-33; pixel rectangle
  * INCLUSIVE as there) + Image::writePixel (image.cpp:44-50).  d_rgb is a DEVICE pointer to
  * width*height*3 floats (pixel (x,y) at (x + y*width)*3), or NULL for the context's own

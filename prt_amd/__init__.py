@@ -105,7 +105,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 EXPORTS = [
     "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
     "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_render_gbuffer", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
-    "prt_hip_comm_unique_id", "prt_hip_comm_init", "prt_hip_comm_adopt", "prt_hip_comm_destroy", "prt_hip_gather_rccl", "prt_hip_gather_payload_bytes",
+    "prt_hip_build_bvh", "prt_hip_comm_unique_id", "prt_hip_comm_init", "prt_hip_comm_adopt", "prt_hip_comm_destroy", "prt_hip_gather_rccl", "prt_hip_gather_payload_bytes",
     "prt_hip_get_stats",
     "prt_host_mesh_cornell", "prt_host_mesh_load_obj", "prt_host_mesh_from_arrays", "prt_host_mesh_displaced_sphere",
     "prt_host_mesh_atrium", "prt_host_mesh_destroy", "prt_host_mesh_transform", "prt_host_mesh_calculate_vertex_normals",
@@ -166,6 +166,7 @@ def _load(path, with_test_entry_points):
     L.prt_hip_download.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     L.prt_hip_render_gbuffer.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, vp, vp]
     L.prt_hip_gather.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.prt_hip_build_bvh.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp, u32p, vp, C.POINTER(C.c_double)]
     L.prt_hip_comm_unique_id.argtypes = [vp]
     L.prt_hip_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.prt_hip_comm_adopt.argtypes = [vp, vp]
@@ -450,6 +451,19 @@ class PathTracer:
     def render(self, samples, **kw):
         W, H = self._camera.width, self._camera.height
         return self.trace_block(0, 0, W - 1, H - 1, samples, **kw)
+
+    def build_bvh(self, indices, positions):
+        """Bvh::build on the GPU (prt_hip_build_bvh): returns (nodes as NODE_DTYPE array, primRemapping, device ms)."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        n = len(idx)
+        nodes = np.zeros(2 * n, dtype=NODE_DTYPE)
+        remap = np.zeros(n, dtype=np.uint32)
+        count, ms = C.c_uint32(), C.c_double()
+        self._chk(self._L.prt_hip_build_bvh(self._ctx, n, idx.ctypes.data_as(C.c_void_p), len(pos), pos.ctypes.data_as(C.c_void_p),
+                                            nodes.ctypes.data_as(C.c_void_p), C.byref(count), remap.ctypes.data_as(C.c_void_p), C.byref(ms)),
+                  "prt_hip_build_bvh")
+        return nodes[:count.value].copy(), remap, ms.value
 
     # ---- multi-process image gather over RCCL (include/prt_hip.h "image gather")
     def comm_init(self, unique_id, rank, nranks):

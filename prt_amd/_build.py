@@ -12,6 +12,7 @@ TEST_LIB = os.path.join(LIB_DIR, "libprt_hip_test.so")  # same sources + -DPRT_T
 SOURCES = [
     "prt_kernels.hip",
     "prt_gather.hip",
+    "prt_bvh_build.hip",
     "host/prt_host.cpp",
     "host/prt_bvh.cpp",
     "host/prt_models.cpp",
@@ -63,7 +64,7 @@ def source_sha16():
     a committed counter summary was taken with the code it is running."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(["prt_kernels.hip", "prt_gather.hip", "prt_frame.h", "prt_device.h", "prt_devmath.h", "prt_internal.h"]):
+    for name in sorted(["prt_kernels.hip", "prt_gather.hip", "prt_bvh_build.hip", "prt_frame.h", "prt_device.h", "prt_devmath.h", "prt_internal.h"]):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -506,6 +506,77 @@ def test_single_process_gather_of_several_contexts(tracer, c1):
             t.close()
 
 
+def _host_bvh(idx, pos):
+    import ctypes as C
+    L = prt_amd.lib()
+    n = len(idx)
+    nodes_p, cnt, remap_p = C.POINTER(prt_amd.BvhNode)(), C.c_uint32(), C.POINTER(C.c_uint32)()
+    assert L.prt_host_bvh_build(n, idx.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), 0, C.byref(nodes_p), C.byref(cnt),
+                                C.byref(remap_p)) == 0
+    nodes = np.frombuffer(C.string_at(nodes_p, cnt.value * C.sizeof(prt_amd.BvhNode)), dtype=T.NODE_DTYPE).copy()
+    remap = np.ctypeslib.as_array(remap_p, shape=(n,)).copy()
+    L.prt_host_free(nodes_p)
+    L.prt_host_free(remap_p)
+    return nodes, remap
+
+
+def _assert_same_tree(nodes, remap, ref_nodes, ref_remap, what):
+    assert len(nodes) == len(ref_nodes), (what, len(nodes), len(ref_nodes))
+    for f in ("primOrSecondNodeIndex", "triVectorIndex", "primCount", "splitAxis"):
+        assert (nodes[f] == ref_nodes[f]).all(), (what, f, int(np.argmax(nodes[f] != ref_nodes[f])))
+    # bounds: equal as floats (the min / max of the same vertices; only the sign of a zero bound can depend on the merge order)
+    assert np.array_equal(nodes["lower"], ref_nodes["lower"]) and np.array_equal(nodes["upper"], ref_nodes["upper"]), what
+    assert (remap == ref_remap).all(), what
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (8, 1), (9, 2), (300, 3), (5000, 4), (70000, 5)])
+def test_gpu_bvh_build_matches_host_builder_on_soups(tracer, n, seed):
+    """prt_hip_build_bvh (level-parallel binned SAH on the device) produces the node array, leaf order and
+    primRemapping of the host builder, which the CPU tests pin against the reference's own Bvh::build -- on the soups that
+    exercise the zero-extent axis (bvh.cpp:66), the unsigned bucket compare (:88), NaN costs of empty sides (:98-125) and
+    the fallback to the middle (:150-153)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-1, 1, (3 * n, 3)).astype(np.float32)
+    if seed == 3:
+        pos[:, 1] = 0.25
+    if seed == 4:
+        pos[: 3 * 64] = pos[0]
+    if seed == 5:
+        pos[: 3 * 2000, 0] = np.float32(0.5)  # a slab of triangles with equal x centroids
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    nodes, remap, ms = tracer.build_bvh(idx, pos)
+    ref_nodes, ref_remap = _host_bvh(idx, pos)
+    _assert_same_tree(nodes, remap, ref_nodes, ref_remap, f"soup n={n} seed={seed}")
+
+
+def test_gpu_bvh_build_matches_reference_fixture_and_large_scenes(tracer):
+    """The device-built arrays equal the REFERENCE builder's for the Cornell box and the teapot (tests/golden/
+    bvh_cornell_teapot.npz, dumped from the compiled reference), and the host builder's on the 262 k and 2.5 M triangle
+    stand-ins; build times are printed."""
+    z = np.load(os.path.join(G, "bvh_cornell_teapot.npz"))
+    desc = T.cornell_scene(512, 512)
+    for i in range(2):
+        mesh = desc.meshes[i]
+        nodes, remap, ms = tracer.build_bvh(mesh.indices, mesh.positions)
+        ref = z[f"nodes{i}"].view(T.NODE_DTYPE).reshape(-1)
+        assert len(nodes) == len(ref), i
+        for f in ("primOrSecondNodeIndex", "primCount", "splitAxis"):
+            assert (nodes[f] == ref[f]).all(), (i, f)
+        leaf = nodes["primCount"] != 0xF
+        assert (nodes["triVectorIndex"][leaf] == ref["triVectorIndex"][leaf]).all()
+        assert np.array_equal(nodes["lower"], ref["lower"]) and np.array_equal(nodes["upper"], ref["upper"])
+        assert (remap == z[f"remap{i}"]).all(), i
+    for tris, seed in ((262000, 1), (2500000, 4)):
+        scene, camera, _ = prt_amd.setup_atrium_standin(64, 64, tris=tris, seed=seed)
+        m = scene.arrays()["meshes"][0]
+        import time
+        t0 = time.time()
+        nodes, remap, ms = tracer.build_bvh(m["indices"], m["positions"])
+        wall = time.time() - t0
+        _assert_same_tree(nodes, remap, m["nodes"], m["remap"], f"atrium {tris}")
+        print(f"GPU BVH build, {len(m['indices'])} triangles: {ms:.1f} ms on the device ({wall * 1e3:.0f} ms with transfers), {len(nodes)} nodes")
+
+
 def test_rccl_gather_single_rank_communicator(tracer, c1):
     """prt_hip_gather_rccl through a real RCCL communicator of ONE rank (all a 1-GPU box allows: RCCL refuses two ranks on one
     device): librccl is found and loaded, ncclCommInitRank / grouped send-recv bookkeeping / stream ordering run, the
