@@ -91,19 +91,45 @@ __device__ __forceinline__ float centroid(const BuildArrays& B, uint32_t prim, u
 __device__ __forceinline__ void key_min(uint32_t* k, float v) { if (v == v) atomicMin(k, fkey(v)); }
 __device__ __forceinline__ void key_max(uint32_t* k, float v) { if (v == v) atomicMax(k, fkey(v)); }
 
-// ---- bounds of the nodes created at the previous step: node->bbox.merge(every vertex), bvh.cpp:45-49
+// ---- bounds of the nodes created at the previous step: node->bbox.merge(every vertex), bvh.cpp:45-49.  Near the root every
+// wave's 64 triangles belong to one node: the wave reduces first and issues 6 atomics instead of 6 * 64 on the same words.
 __global__ void bounds_kernel(BuildArrays B, uint32_t firstNew)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
-    const uint32_t node = B.posNode[i];
-    if (node < firstNew) return;
-    const uint32_t prim = B.remap[i];
-    uint32_t* box = B.nBox + 6 * (size_t)node;
-    for (uint32_t j = 0; j < 3; j++) {
-        const float3 v = vtx(B, prim, j);
-        key_min(box + 0, v.x); key_min(box + 1, v.y); key_min(box + 2, v.z);
-        key_max(box + 3, v.x); key_max(box + 4, v.y); key_max(box + 5, v.z);
+    const bool in = i < B.n;
+    const uint32_t node = in ? B.posNode[i] : kNone;
+    const bool work = in && node >= firstNew;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (work) {
+        const uint32_t prim = B.remap[i];
+        for (uint32_t j = 0; j < 3; j++) {
+            const float3 v = vtx(B, prim, j);
+            lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+            hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+        }
+    }
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+    const bool uniform = __all(node == first); // the whole wave (idle lanes included: their node is kNone) in one node
+    if (uniform) {
+        if (first == kNone || first < firstNew) return;
+        for (int o = 32; o > 0; o >>= 1)
+            for (int d = 0; d < 3; d++) {
+                lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+                hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+            }
+        if ((threadIdx.x & 63u) == 0u) {
+            uint32_t* box = B.nBox + 6 * (size_t)first;
+            for (int d = 0; d < 3; d++) {
+                key_min(box + d, lo[d]);
+                key_max(box + 3 + d, hi[d]);
+            }
+        }
+    } else if (work) {
+        uint32_t* box = B.nBox + 6 * (size_t)node;
+        for (int d = 0; d < 3; d++) {
+            key_min(box + d, lo[d]);
+            key_max(box + 3 + d, hi[d]);
+        }
     }
 }
 
@@ -140,41 +166,78 @@ __device__ __forceinline__ int32_t to_int(float f)
     return (int32_t)f;
 }
 
-// ---- bins (bvh.cpp:66-96): for each axis the triangle's bucket takes its count and bounds
-__global__ void bin_kernel(BuildArrays B)
+// ---- bins (bvh.cpp:66-96): for each axis the triangle's bucket takes its count and bounds.  A block whose 256 triangles
+// belong to one node (every block near the root) collects them in LDS and adds only its non-empty bins to the node's.
+__global__ __launch_bounds__(256) void bin_kernel(BuildArrays B)
 {
+    __shared__ uint32_t sBins[3 * kBuckets * kBinWords];
+    __shared__ uint32_t sNode[2]; // min and max node id of the block
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B.n) return;
-    const uint32_t node = B.posNode[i];
-    const uint32_t slot = B.nSlot[node];
-    if (slot == kNone) return;
-    const uint32_t prim = B.remap[i];
-    const uint32_t* box = B.nBox + 6 * (size_t)node;
-    float lo[3], hi[3], sum[3] = {0.0f, 0.0f, 0.0f};
-    lo[0] = lo[1] = lo[2] = FLT_MAX;
-    hi[0] = hi[1] = hi[2] = -FLT_MAX;
-    for (uint32_t j = 0; j < 3; j++) {
-        const float3 v = vtx(B, prim, j);
-        const float c[3] = {v.x, v.y, v.z};
-        for (int d = 0; d < 3; d++) {
-            sum[d] = sum[d] + c[d];
-            lo[d] = fminf(lo[d], c[d]);
-            hi[d] = fmaxf(hi[d], c[d]);
+    const bool in = i < B.n;
+    const uint32_t node = in ? B.posNode[i] : kNone;
+    if (threadIdx.x == 0) {
+        sNode[0] = kNone;
+        sNode[1] = 0;
+    }
+    for (uint32_t k = threadIdx.x; k < 3 * kBuckets; k += blockDim.x) {
+        uint32_t* b = sBins + k * kBinWords;
+        b[0] = 0;
+        b[1] = b[2] = b[3] = KEY_MAX_FLT;
+        b[4] = b[5] = b[6] = KEY_LOWEST_FLT;
+    }
+    __syncthreads();
+    if (in) {
+        atomicMin(&sNode[0], node);
+        atomicMax(&sNode[1], node);
+    }
+    __syncthreads();
+    const bool uniform = sNode[0] == sNode[1]; // (a partial last block is uniform when its real triangles are)
+    const uint32_t slot = in ? B.nSlot[node] : kNone;
+    if (slot != kNone) {
+        const uint32_t prim = B.remap[i];
+        const uint32_t* box = B.nBox + 6 * (size_t)node;
+        float lo[3], hi[3], sum[3] = {0.0f, 0.0f, 0.0f};
+        lo[0] = lo[1] = lo[2] = FLT_MAX;
+        hi[0] = hi[1] = hi[2] = -FLT_MAX;
+        for (uint32_t j = 0; j < 3; j++) {
+            const float3 v = vtx(B, prim, j);
+            const float c[3] = {v.x, v.y, v.z};
+            for (int d = 0; d < 3; d++) {
+                sum[d] = sum[d] + c[d];
+                lo[d] = fminf(lo[d], c[d]);
+                hi[d] = fmaxf(hi[d], c[d]);
+            }
+        }
+        for (uint32_t dim = 0; dim < 3; dim++) {
+            const float lower = funkey(box[dim]), upper = funkey(box[3 + dim]);
+            const float extent = upper - lower;
+            const float splitExtent = extent == 0.0f ? 0.0001f : extent; // bvh.cpp:67
+            const float c = (1.0f / 3.0f) * sum[dim];
+            int32_t b = to_int((float)kBuckets * (c - lower) / splitExtent);
+            if ((uint32_t)b >= kBuckets) b = (int32_t)kBuckets - 1; // :88, an unsigned compare
+            uint32_t* bin = uniform ? sBins + (dim * kBuckets + (uint32_t)b) * kBinWords
+                                    : B.bins + (((size_t)slot * 3 + dim) * kBuckets + (uint32_t)b) * kBinWords;
+            atomicAdd(bin, 1u);
+            for (int d = 0; d < 3; d++) {
+                key_min(bin + 1 + d, lo[d]);
+                key_max(bin + 4 + d, hi[d]);
+            }
         }
     }
-    for (uint32_t dim = 0; dim < 3; dim++) {
-        const float lower = funkey(box[dim]), upper = funkey(box[3 + dim]);
-        const float extent = upper - lower;
-        const float splitExtent = extent == 0.0f ? 0.0001f : extent; // bvh.cpp:67
-        const float c = (1.0f / 3.0f) * sum[dim];
-        int32_t b = to_int((float)kBuckets * (c - lower) / splitExtent);
-        if ((uint32_t)b >= kBuckets) b = (int32_t)kBuckets - 1; // :88, an unsigned compare
-        uint32_t* bin = B.bins + (((size_t)slot * 3 + dim) * kBuckets + (uint32_t)b) * kBinWords;
-        atomicAdd(bin, 1u);
-        for (int d = 0; d < 3; d++) {
-            key_min(bin + 1 + d, lo[d]);
-            key_max(bin + 4 + d, hi[d]);
-        }
+    __syncthreads();
+    if (uniform && sNode[0] != kNone) {
+        const uint32_t bslot = B.nSlot[sNode[0]];
+        if (bslot != kNone)
+            for (uint32_t k = threadIdx.x; k < 3 * kBuckets; k += blockDim.x) {
+                const uint32_t* sb = sBins + k * kBinWords;
+                if (sb[0] == 0u) continue;
+                uint32_t* gb = B.bins + ((size_t)bslot * 3 * kBuckets + k) * kBinWords;
+                atomicAdd(gb, sb[0]);
+                for (int d = 0; d < 3; d++) {
+                    atomicMin(gb + 1 + d, sb[1 + d]);
+                    atomicMax(gb + 4 + d, sb[4 + d]);
+                }
+            }
     }
 }
 
@@ -250,11 +313,14 @@ __global__ void flag_kernel(BuildArrays B)
     const uint32_t node = B.posNode[i];
     const uint32_t slot = B.nSlot[node];
     uint32_t f = 0;
-    if (slot != kNone) {
-        f = centroid(B, B.remap[i], B.nAxis[node]) < B.splitPos[slot] ? 1u : 0u;
-        if (!f) atomicMin(&B.firstRight[slot], i);
-    }
+    if (slot != kNone) f = centroid(B, B.remap[i], B.nAxis[node]) < B.splitPos[slot] ? 1u : 0u;
     B.flag[i] = f;
+    // the first position of the node that stays right: one atomic per wave and node run instead of one per triangle
+    const bool right = slot != kNone && !f;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t prevNode = (uint32_t)__shfl_up((int)node, 1, 64);
+    const bool prevRight = __shfl_up((int)right, 1, 64) != 0;
+    if (right && (lane == 0 || prevNode != node || !prevRight)) atomicMin(&B.firstRight[slot], i);
 }
 
 // ---- the reference's partition loop (bvh.cpp:137-150) in closed form.  With c0 = the first position whose triangle stays
