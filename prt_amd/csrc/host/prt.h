@@ -153,6 +153,9 @@ class Bvh
 public:
     Bvh() = default;
     void build(Mesh&& mesh);
+    // The same tree, built on the GPU (prt_hip_build_bvh: level-parallel binned SAH, identical node array, leaf order and
+    // primRemapping).  `device` < 0 or no HIP device: falls back to build() -- scene set-up must work on any host.
+    void buildOnDevice(Mesh&& mesh, int device = 0);
     const std::vector<prt_bvh_node>& getNodes() const { return m_nodes; }
     const std::vector<uint32_t>& getPrimRemapping() const { return m_primRemapping; }
     const Mesh& getMesh() const { return m_mesh; }

@@ -604,6 +604,27 @@ void TotalStats::print() // stats.h:59-66
     logPrintf(LogLevel::kInfo, "Tri tested: %.3fM(%llu)\n", totalTriTested.load() * kToM, (unsigned long long)totalTriTested.load());
 }
 
+void Bvh::buildOnDevice(Mesh&& mesh, int device)
+{
+    if (device < 0 || prt_hip_device_count() <= device || mesh.getPrimCount() == 0) {
+        build(std::move(mesh));
+        return;
+    }
+    std::lock_guard<std::mutex> g(g_deviceMutex);
+    DeviceSlot& slot = g_devices[device];
+    if (!slot.ctx && prt_hip_create(device, &slot.ctx) != PRT_HIP_OK) die("prt_hip_create");
+    m_mesh = std::move(mesh);
+    const uint32_t n = m_mesh.getPrimCount();
+    m_nodes.resize((size_t)2 * n);
+    m_primRemapping.resize(n);
+    uint32_t count = 0;
+    if (prt_hip_build_bvh(slot.ctx, n, m_mesh.getIndexBuffer(), m_mesh.getVertexCount(), &m_mesh.getPositionBuffer()->x, m_nodes.data(), &count,
+                          m_primRemapping.data(), nullptr) != PRT_HIP_OK)
+        die("prt_hip_build_bvh");
+    m_nodes.resize(count);
+    logPrintf(LogLevel::kVerbose, "LinearBvhNode (count=%u, built on device %d)\n", (unsigned)m_nodes.size(), device);
+}
+
 void PathTracer::releaseDevice()
 {
     std::lock_guard<std::mutex> g(g_deviceMutex);

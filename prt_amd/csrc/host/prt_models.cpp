@@ -236,8 +236,8 @@ static bool decodeTga(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
     return true;
 }
 
-// ... and PNG: 8 bits per sample, grey / grey+alpha / RGB / RGBA / palette (with tRNS), not interlaced.  A plain inflate
-// (RFC 1951: stored, fixed and dynamic Huffman blocks) and the five scanline filters (PNG 1.2 section 6).
+// ... and PNG (see decodePng).  A plain inflate (RFC 1951: stored, fixed and dynamic Huffman blocks) and the five scanline
+// filters (PNG 1.2 section 6).
 namespace {
 struct BitReader {
     const uint8_t* p;
@@ -361,6 +361,10 @@ bool inflateZlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out)
 }
 } // namespace
 
+// PNG as stb_image hands it to Texture::load (texture.cpp:218-249, 8 bits per channel requested): every colour type, bit depths
+// 1 / 2 / 4 / 8 / 16, Adam7 interlace, palette and colour-key transparency (tRNS).  Samples below 8 bits are scaled to 0..255
+// (x 255, x 85, x 17), 16-bit samples keep their high byte, a colour key adds an alpha channel that is 0 where the pixel
+// equals the key -- the conversions stb_image applies (stbi__depth_scale_table, stbi__convert_16_to_8, stbi__compute_transparency).
 static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>& raw)
 {
     std::vector<uint8_t> file;
@@ -369,7 +373,7 @@ static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (file.size() < 8 || memcmp(file.data(), sig, 8)) return false;
     auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | (file[o + 1] << 16) | (file[o + 2] << 8) | file[o + 3]; };
-    int colorType = -1;
+    int colorType = -1, bits = 0, interlace = 0;
     std::vector<uint8_t> idat, palette, trns;
     for (size_t o = 8; o + 12 <= file.size();) {
         uint32_t len = be32(o);
@@ -379,8 +383,10 @@ static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
             if (len < 13) return false;
             w = (int)be32(o + 8);
             h = (int)be32(o + 12);
-            if (d[8] != 8 || d[10] != 0 || d[11] != 0 || d[12] != 0) return false; // 8 bits per sample, no interlace
+            bits = d[8];
             colorType = d[9];
+            interlace = d[12];
+            if (d[10] != 0 || d[11] != 0 || interlace > 1) return false;
         } else if (!memcmp(&file[o + 4], "PLTE", 4)) palette.assign(d, d + len);
         else if (!memcmp(&file[o + 4], "tRNS", 4)) trns.assign(d, d + len);
         else if (!memcmp(&file[o + 4], "IDAT", 4)) idat.insert(idat.end(), d, d + len);
@@ -389,42 +395,88 @@ static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
     }
     const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
     if (!channels || w <= 0 || h <= 0 || w > 65535 || h > 65535) return false;
+    const bool okDepth = (colorType == 0 && (bits == 1 || bits == 2 || bits == 4 || bits == 8 || bits == 16)) ||
+                         (colorType == 3 && (bits == 1 || bits == 2 || bits == 4 || bits == 8)) ||
+                         ((colorType == 2 || colorType == 4 || colorType == 6) && (bits == 8 || bits == 16));
+    if (!okDepth) return false;
     std::vector<uint8_t> data;
     if (!inflateZlib(idat, data)) return false;
-    const size_t stride = (size_t)w * channels;
-    if (data.size() < (stride + 1) * (size_t)h) return false;
-    std::vector<uint8_t> img(stride * h);
-    for (int y = 0; y < h; y++) {
-        const uint8_t* src = &data[(stride + 1) * y];
-        uint8_t* cur = &img[stride * y];
-        const uint8_t* up = y ? cur - stride : nullptr;
-        const int ft = src[0];
-        if (ft > 4) return false;
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= (size_t)channels ? cur[i - channels] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)channels) ? up[i - channels] : 0, pr = 0;
-            if (ft == 1) pr = a;
-            else if (ft == 2) pr = b;
-            else if (ft == 3) pr = (a + b) >> 1;
-            else if (ft == 4) {
-                int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-                pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    // samples of the whole image, 16 bits each (as stored: not yet scaled)
+    std::vector<uint16_t> img((size_t)w * h * channels);
+    const size_t bpp = std::max<size_t>(1, (size_t)channels * bits / 8); // the filters' "corresponding byte" distance
+    static const int x0s[8] = {0, 0, 4, 0, 2, 0, 1, 0}, y0s[8] = {0, 0, 0, 4, 0, 2, 0, 1}, dxs[8] = {1, 8, 8, 4, 4, 2, 2, 1}, dys[8] = {1, 8, 8, 8, 4, 4, 2, 2};
+    size_t at = 0;
+    std::vector<uint8_t> prev, cur;
+    for (int pass = interlace ? 1 : 0; pass <= (interlace ? 7 : 0); pass++) {
+        const int pw = (w - x0s[pass] + dxs[pass] - 1) / dxs[pass], ph = (h - y0s[pass] + dys[pass] - 1) / dys[pass];
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = ((size_t)pw * channels * bits + 7) / 8;
+        prev.assign(stride, 0);
+        cur.resize(stride);
+        for (int y = 0; y < ph; y++) {
+            if (at + 1 + stride > data.size()) return false;
+            const uint8_t* src = &data[at];
+            at += 1 + stride;
+            const int ft = src[0];
+            if (ft > 4) return false;
+            for (size_t i = 0; i < stride; i++) {
+                int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, pr = 0;
+                if (ft == 1) pr = a;
+                else if (ft == 2) pr = b;
+                else if (ft == 3) pr = (a + b) >> 1;
+                else if (ft == 4) {
+                    int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                    pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                }
+                cur[i] = (uint8_t)(src[1 + i] + pr);
             }
-            cur[i] = (uint8_t)(src[1 + i] + pr);
+            const int oy = y0s[pass] + y * dys[pass];
+            for (int x = 0; x < pw; x++) {
+                const int ox = x0s[pass] + x * dxs[pass];
+                for (int ch = 0; ch < channels; ch++) {
+                    const size_t k = (size_t)x * channels + ch;
+                    uint16_t v;
+                    if (bits == 16) v = (uint16_t)((cur[2 * k] << 8) | cur[2 * k + 1]);
+                    else if (bits == 8) v = cur[k];
+                    else v = (uint16_t)((cur[k * bits / 8] >> (8 - bits - (k * bits) % 8)) & ((1 << bits) - 1));
+                    img[((size_t)oy * w + ox) * channels + ch] = v;
+                }
+            }
+            prev.swap(cur);
         }
     }
+    const size_t px = (size_t)w * h;
     if (colorType == 3) { // palette -> RGB(A)
         if (palette.size() < 3) return false;
         depth = trns.empty() ? 3 : 4;
-        raw.resize((size_t)w * h * depth);
-        for (size_t i = 0; i < (size_t)w * h; i++) {
+        raw.resize(px * depth);
+        for (size_t i = 0; i < px; i++) {
             size_t k = img[i];
             if (3 * k + 2 >= palette.size()) return false;
             raw[depth * i + 0] = palette[3 * k]; raw[depth * i + 1] = palette[3 * k + 1]; raw[depth * i + 2] = palette[3 * k + 2];
             if (depth == 4) raw[depth * i + 3] = k < trns.size() ? trns[k] : 255;
         }
-    } else {
-        depth = channels;
-        raw.swap(img);
+        return true;
+    }
+    // colour key (tRNS with colour types 0 and 2): one 16-bit value per channel, compared with the samples as stored
+    const bool keyed = (colorType == 0 && trns.size() >= 2) || (colorType == 2 && trns.size() >= 6);
+    uint16_t key[3] = {0, 0, 0};
+    if (keyed)
+        for (int ch = 0; ch < channels; ch++) {
+            key[ch] = (uint16_t)((trns[2 * ch] << 8) | trns[2 * ch + 1]);
+            if (bits < 16) key[ch] &= 255; // stb_image keeps the low byte of the key for 8-bit data
+        }
+    static const int scale[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};
+    depth = channels + (keyed ? 1 : 0);
+    raw.resize(px * depth);
+    for (size_t i = 0; i < px; i++) {
+        bool isKey = keyed;
+        for (int ch = 0; ch < channels; ch++) {
+            const uint16_t v = img[i * channels + ch];
+            if (keyed && v != key[ch]) isKey = false;
+            raw[i * depth + ch] = bits == 16 ? (uint8_t)(v >> 8) : (uint8_t)(v * scale[bits]);
+        }
+        if (keyed) raw[i * depth + channels] = isKey ? 0 : 255;
     }
     return true;
 }

@@ -338,6 +338,106 @@ def test_obj_mtl_reader_decodes_png_maps(L, tmp_path, level, strategy):
         assert np.array_equal(b["textures"][0], want), name
 
 
+def _png_general(path, samples, bits, ctype, interlace=False, palette=None, trns=None):
+    """Write a PNG of any colour type / bit depth, optionally Adam7-interlaced.  samples: (h, w, channels) integers < 2**bits."""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+    bpp = max(1, ch * bits // 8)
+
+    def pack_rows(sub):
+        ph, pw, _ = sub.shape
+        out = bytearray()
+        prev = np.zeros(((pw * ch * bits + 7) // 8,), dtype=np.int32)
+        for y in range(ph):
+            flat = sub[y].reshape(-1).astype(np.uint32)
+            if bits == 16:
+                row = np.stack([flat >> 8, flat & 255], axis=1).reshape(-1)
+            elif bits == 8:
+                row = flat
+            else:
+                per = 8 // bits
+                padded = np.concatenate([flat, np.zeros((-len(flat)) % per, dtype=np.uint32)]).reshape(-1, per)
+                row = sum(padded[:, k] << (8 - bits * (k + 1)) for k in range(per))
+            cur = row.astype(np.int32)
+            ft = (y + pw) % 5
+            a = np.concatenate([np.zeros(bpp, dtype=np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (a + prev) // 2
+            else:
+                pp = a + prev - c
+                pa, pb, pc = abs(pp - a), abs(pp - prev), abs(pp - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            out += bytes([ft]) + ((cur - pred) & 0xff).astype(np.uint8).tobytes()
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        x0s, y0s, dxs, dys = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+        body = b"".join(pack_rows(samples[y0::dy, x0::dx]) for x0, y0, dx, dy in zip(x0s, y0s, dxs, dys) if samples[y0::dy, x0::dx].size)
+    else:
+        body = pack_rows(samples)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bits, ctype, 0, 0, 1 if interlace else 0)))
+        if palette is not None:
+            f.write(chunk(b"PLTE", palette.astype(np.uint8).tobytes()))
+        if trns is not None:
+            f.write(chunk(b"tRNS", bytes(trns)))
+        f.write(chunk(b"IDAT", zlib.compress(body, 6)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_bit_depths_interlace_and_colour_keys(L, tmp_path, interlace):
+    """The PNG files stb_image accepts beyond plain 8-bit ones (texture.cpp:218-249 asks it for 8 bits per channel): 16-bit
+    samples keep their high byte, 1 / 2 / 4-bit grey is scaled to 0..255, palettes of 1 / 2 / 4 bits, Adam7 interlace, and a
+    colour key (tRNS) adds an alpha channel that is 0 exactly where the pixel equals the key."""
+    import struct
+    rng = np.random.default_rng(11)
+    h, w = 11, 13  # not multiples of 8: every Adam7 pass has a ragged edge
+
+    def load(name):
+        (tmp_path / "n.mtl").write_text(f"newmtl a\nKd 1 1 1\nmap_Kd {name}\n")
+        (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+        sc = prt_amd.Scene()
+        sc.add(prt_amd.Mesh.load_obj(str(tmp_path / "n.obj")))
+        return sc.arrays()["textures"][0]
+
+    def rgba(x):  # what Texture::load keeps (texture.cpp:218-249): one channel for a grey file, else RGBA (alpha 255 if the file has none)
+        if x.shape[2] == 1: pass
+        elif x.shape[2] == 2: x = np.dstack([x[..., 0], x[..., 0], x[..., 0], x[..., 1]])
+        elif x.shape[2] == 3: x = np.dstack([x, np.full(x.shape[:2], 255)])
+        return x.astype(np.uint8)
+
+    for ch, ctype in ((1, 0), (2, 4), (3, 2), (4, 6)):  # 16 bits per sample
+        v = rng.integers(0, 65536, size=(h, w, ch))
+        _png_general(tmp_path / "a.png", v, 16, ctype, interlace)
+        assert np.array_equal(load("a.png"), rgba(v >> 8)), (ch, "16-bit")
+    for bits, scale in ((1, 255), (2, 85), (4, 17)):  # grey below 8 bits, and palettes
+        v = rng.integers(0, 1 << bits, size=(h, w, 1))
+        _png_general(tmp_path / "g.png", v, bits, 0, interlace)
+        assert np.array_equal(load("g.png"), rgba(v * scale)), (bits, "grey")
+        pal = rng.integers(0, 256, size=(1 << bits, 3))
+        _png_general(tmp_path / "p.png", v, bits, 3, interlace, palette=pal)
+        assert np.array_equal(load("p.png"), rgba(pal[v[..., 0]])), (bits, "palette")
+    # colour keys: 8-bit RGB, 16-bit grey
+    v = rng.integers(0, 256, size=(h, w, 3))
+    v[2:5, 3:6] = (10, 200, 30)
+    _png_general(tmp_path / "k.png", v, 8, 2, interlace, trns=struct.pack(">HHH", 10, 200, 30))
+    want = np.dstack([v, np.where((v == (10, 200, 30)).all(-1), 0, 255)]).astype(np.uint8)
+    assert np.array_equal(load("k.png"), want)
+    g = rng.integers(0, 65536, size=(h, w, 1))
+    g[1, 1] = g[7, 9] = 0x1234
+    _png_general(tmp_path / "k16.png", g, 16, 0, interlace, trns=struct.pack(">H", 0x1234))
+    want = np.dstack([g[..., 0] >> 8] * 3 + [np.where(g[..., 0] == 0x1234, 0, 255)]).astype(np.uint8)
+    assert np.array_equal(load("k16.png"), want)
+
+
 def test_exr_and_ppm_writers(L, tmp_path):
     """Image::saveExr (image.cpp:82-139): half-float B, G, R planes -- written here as an uncompressed scan-line OpenEXR;
     parsed back, every sample must be the round-to-nearest-even half of the float.  Image::savePpm (image.cpp:52-80)."""
