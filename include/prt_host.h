@@ -53,7 +53,7 @@ void prt_host_scene_bbox(const prt_host_scene* s, float lowerUpper[6]);
 
 /* Image::saveExr (image.cpp:82-139: half-float B,G,R OpenEXR) and Image::savePpm (image.cpp:52-80: tone map, gamma, 8 bit)
  * for a float RGB image of width*height*3 values, row 0 first; 0 or -1 */
-int prt_host_save_exr(const char* path, uint32_t width, uint32_t height, const float* rgb);
+int prt_host_save_exr(const char* path, uint32_t width, uint32_t height, const float* rgb, int zip /* 1: ZIP blocks (tinyexr's default), 0: raw */);
 int prt_host_save_ppm(const char* path, uint32_t width, uint32_t height, const float* rgb, int tonemap);
 
 /* Camera::create (camera.h:17-36) */

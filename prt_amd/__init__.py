@@ -208,7 +208,7 @@ def _load(path, with_test_entry_points):
     L.prt_host_scene_set_env_light.argtypes = [vp, C.c_int32, C.c_int32, vp]
     L.prt_host_scene_set_env_light.restype = None
     L.prt_host_scene_load_env_light.argtypes = [vp, C.c_char_p]
-    L.prt_host_save_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    L.prt_host_save_exr.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.prt_host_save_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_int]
     L.prt_host_scene_describe.argtypes = [vp]
     L.prt_host_scene_describe.restype = C.POINTER(SceneDesc)
@@ -591,10 +591,11 @@ def owned_pixel_mask(width, height, rank, nranks, tile=16):
     return ((ty * tiles_x + tx) % nranks) == rank
 
 
-def save_exr(path, rgb):
-    """Image::saveExr (image.cpp:82-139): (H, W, 3) float image -> half-float OpenEXR with channels B, G, R."""
+def save_exr(path, rgb, zip=True):
+    """Image::saveExr (image.cpp:82-139): (H, W, 3) float image -> half-float OpenEXR with channels B, G, R (ZIP blocks like
+    tinyexr's default, or raw scan lines)."""
     a = np.ascontiguousarray(rgb, dtype=np.float32)
-    _check(lib().prt_host_save_exr(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)), "prt_host_save_exr")
+    _check(lib().prt_host_save_exr(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p), int(zip)), "prt_host_save_exr")
 
 
 def save_ppm(path, rgb, tonemap=True):

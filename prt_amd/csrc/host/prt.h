@@ -263,7 +263,7 @@ public:
     Image(uint32_t width, uint32_t height, bool tonemap = true, float exposure = 1.0f);
     void writePixel(uint32_t x, uint32_t y, const Vector3f& color); // image.cpp:44-50
     void savePpm(const char* path) const;                            // image.cpp:52-80
-    void saveExr(const char* path) const;                            // image.cpp:82-139: half-float B,G,R OpenEXR (uncompressed scan lines)
+    void saveExr(const char* path, bool zip = true) const;           // image.cpp:82-139: half-float B,G,R OpenEXR, ZIP blocks like tinyexr's default
     void savePfm(const char* path) const;
     uint32_t getWidth() const { return m_width; }
     uint32_t getHeigit() const { return m_height; }

@@ -434,10 +434,110 @@ static uint16_t floatToHalf(float f)
     return (uint16_t)(sign | h);
 }
 
-// image.cpp:82-139: three half-float channels named B, G, R (the reference converts float -> half through tinyexr).  Written
-// here directly as an uncompressed scan-line OpenEXR 2.0 file: magic, version, header attributes, line offset table, one
-// block per scan line with the channels in name order.
-void Image::saveExr(const char* path) const
+// ---- a small deflate (RFC 1951) for the EXR writer: LZ77 over a hash of 3-byte strings, fixed Huffman codes, zlib framing
+namespace
+{
+struct BitWriter {
+    std::vector<uint8_t>& out;
+    uint32_t acc = 0;
+    int cnt = 0;
+    void put(uint32_t v, int n) // n bits, least significant first
+    {
+        acc |= v << cnt;
+        cnt += n;
+        while (cnt >= 8) {
+            out.push_back((uint8_t)acc);
+            acc >>= 8;
+            cnt -= 8;
+        }
+    }
+    void putCode(uint32_t code, int n) // Huffman codes go most significant bit first
+    {
+        uint32_t r = 0;
+        for (int i = 0; i < n; i++) r |= ((code >> i) & 1u) << (n - 1 - i);
+        put(r, n);
+    }
+    void flush()
+    {
+        if (cnt) out.push_back((uint8_t)acc);
+        acc = 0;
+        cnt = 0;
+    }
+};
+
+void zlibCompress(const uint8_t* in, size_t n, std::vector<uint8_t>& out)
+{
+    out.clear();
+    out.push_back(0x78);
+    out.push_back(0x9c);
+    BitWriter bw{out};
+    bw.put(1, 1); // last block
+    bw.put(1, 2); // fixed Huffman codes
+    auto literal = [&](uint32_t v) {
+        if (v < 144) bw.putCode(0x30 + v, 8);
+        else bw.putCode(0x190 + (v - 144), 9);
+    };
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    std::vector<int32_t> head(1 << 15, -1), prev(n ? n : 1, -1);
+    auto hash3 = [&](size_t i) { return ((uint32_t)in[i] * 2654435761u ^ (uint32_t)in[i + 1] * 40503u ^ (uint32_t)in[i + 2] * 2246822519u) >> 17; };
+    size_t i = 0;
+    while (i < n) {
+        size_t bestLen = 0, bestDist = 0;
+        if (i + 3 <= n) {
+            const uint32_t hsh = hash3(i);
+            int tries = 32;
+            for (int32_t c = head[hsh]; c >= 0 && tries-- > 0 && i - (size_t)c <= 32768; c = prev[c]) {
+                size_t l = 0;
+                while (l < 258 && i + l < n && in[c + l] == in[i + l]) l++;
+                if (l > bestLen) {
+                    bestLen = l;
+                    bestDist = i - (size_t)c;
+                    if (l == 258) break;
+                }
+            }
+        }
+        const size_t step = bestLen >= 3 ? bestLen : 1;
+        if (bestLen >= 3) {
+            int ls = 28;
+            while (lbase[ls] > bestLen) ls--;
+            const uint32_t sym = 257 + ls;
+            if (sym < 280) bw.putCode(sym - 256, 7);
+            else bw.putCode(0xc0 + (sym - 280), 8);
+            bw.put((uint32_t)(bestLen - lbase[ls]), lext[ls]);
+            int ds = 29;
+            while (dbase[ds] > bestDist) ds--;
+            bw.putCode((uint32_t)ds, 5);
+            bw.put((uint32_t)(bestDist - dbase[ds]), dext[ds]);
+        } else {
+            literal(in[i]);
+        }
+        for (size_t k = 0; k < step; k++, i++)
+            if (i + 3 <= n) {
+                const uint32_t hsh = hash3(i);
+                prev[i] = head[hsh];
+                head[hsh] = (int32_t)i;
+            }
+    }
+    bw.putCode(0, 7); // end of block
+    bw.flush();
+    uint32_t a = 1, bsum = 0; // Adler-32
+    for (size_t k = 0; k < n; k++) {
+        a = (a + in[k]) % 65521u;
+        bsum = (bsum + a) % 65521u;
+    }
+    const uint32_t adler = (bsum << 16) | a;
+    for (int sh = 24; sh >= 0; sh -= 8) out.push_back((uint8_t)(adler >> sh));
+}
+} // namespace
+
+// image.cpp:82-139: three half-float channels named B, G, R (the reference converts float -> half through tinyexr, whose
+// SaveEXRImageToFile compresses with ZIP by default).  Written here directly as a scan-line OpenEXR 2.0 file: magic, version,
+// header attributes, offset table, then blocks of 16 scan lines (ZIP: bytes split into even / odd halves, delta-predicted,
+// deflated; a block that does not shrink is stored raw, as the format prescribes) or of one raw scan line (zip = false).
+void Image::saveExr(const char* path, bool zip) const
 {
     FILE* fp = fopen(path, "wb");
     if (!fp) {
@@ -462,7 +562,7 @@ void Image::saveExr(const char* path) const
         putI(1);
     }
     hd.push_back(0);
-    attr("compression", "compression", 1); hd.push_back(0); // NO_COMPRESSION
+    attr("compression", "compression", 1); hd.push_back(zip ? 3 : 0); // ZIP_COMPRESSION (16 lines per block) / NO_COMPRESSION
     attr("dataWindow", "box2i", 16); putI(0); putI(0); putI((int32_t)m_width - 1); putI((int32_t)m_height - 1);
     attr("displayWindow", "box2i", 16); putI(0); putI(0); putI((int32_t)m_width - 1); putI((int32_t)m_height - 1);
     attr("lineOrder", "lineOrder", 1); hd.push_back(0); // increasing y
@@ -470,22 +570,47 @@ void Image::saveExr(const char* path) const
     attr("screenWindowCenter", "v2f", 8); putF(0.0f); putF(0.0f);
     attr("screenWindowWidth", "float", 4); putF(1.0f);
     hd.push_back(0);
-    const uint64_t lineBytes = 8 + (uint64_t)m_width * 3 * 2;
-    uint64_t offset = hd.size() + (uint64_t)m_height * 8;
-    for (uint32_t y = 0; y < m_height; y++, offset += lineBytes) put(&offset, 8);
-    fwrite(hd.data(), 1, hd.size(), fp);
-    std::vector<uint16_t> line((size_t)m_width * 3);
-    for (uint32_t y = 0; y < m_height; y++) {
-        const float* px = &m_pixels[(size_t)y * m_width * 3];
-        for (uint32_t x = 0; x < m_width; x++) {
-            line[x] = floatToHalf(px[3 * x + 2]);                       // B
-            line[(size_t)m_width + x] = floatToHalf(px[3 * x + 1]);     // G
-            line[(size_t)2 * m_width + x] = floatToHalf(px[3 * x + 0]); // R
+    const uint32_t linesPerBlock = zip ? 16u : 1u, blocks = (m_height + linesPerBlock - 1) / linesPerBlock;
+    std::vector<std::vector<uint8_t>> payload(blocks);
+    std::vector<uint16_t> raw;
+    std::vector<uint8_t> shuffled, packed;
+    for (uint32_t b = 0; b < blocks; b++) {
+        const uint32_t y0 = b * linesPerBlock, y1 = std::min(m_height, y0 + linesPerBlock);
+        raw.assign((size_t)(y1 - y0) * m_width * 3, 0);
+        for (uint32_t y = y0; y < y1; y++) {
+            const float* px = &m_pixels[(size_t)y * m_width * 3];
+            uint16_t* line = &raw[(size_t)(y - y0) * m_width * 3];
+            for (uint32_t x = 0; x < m_width; x++) {
+                line[x] = floatToHalf(px[3 * x + 2]);                       // B
+                line[(size_t)m_width + x] = floatToHalf(px[3 * x + 1]);     // G
+                line[(size_t)2 * m_width + x] = floatToHalf(px[3 * x + 0]); // R
+            }
         }
-        const int32_t yy = (int32_t)y, size = (int32_t)(line.size() * 2);
+        const uint8_t* bytes = (const uint8_t*)raw.data();
+        const size_t n = raw.size() * 2;
+        if (zip) {
+            shuffled.resize(n);
+            const size_t half = (n + 1) / 2;
+            for (size_t k = 0; k < n; k++) shuffled[(k & 1) ? half + k / 2 : k / 2] = bytes[k];
+            for (size_t k = n; k-- > 1;) shuffled[k] = (uint8_t)(shuffled[k] - shuffled[k - 1] + 128);
+            zlibCompress(shuffled.data(), n, packed);
+            if (packed.size() < n) payload[b] = packed;
+            else payload[b].assign(bytes, bytes + n);
+        } else {
+            payload[b].assign(bytes, bytes + n);
+        }
+    }
+    uint64_t offset = hd.size() + (uint64_t)blocks * 8;
+    for (uint32_t b = 0; b < blocks; b++) {
+        put(&offset, 8);
+        offset += 8 + payload[b].size();
+    }
+    fwrite(hd.data(), 1, hd.size(), fp);
+    for (uint32_t b = 0; b < blocks; b++) {
+        const int32_t yy = (int32_t)(b * linesPerBlock), size = (int32_t)payload[b].size();
         fwrite(&yy, 4, 1, fp);
         fwrite(&size, 4, 1, fp);
-        fwrite(line.data(), 2, line.size(), fp);
+        fwrite(payload[b].data(), 1, payload[b].size(), fp);
     }
     fclose(fp);
     printf("Saved %s\n", path);

@@ -139,20 +139,20 @@ const prt_scene_desc* prt_host_scene_describe(prt_host_scene* s)
     return &s->desc;
 }
 
-static int saveImage(const char* path, uint32_t w, uint32_t h, const float* rgb, bool tonemap, bool exr)
+static int saveImage(const char* path, uint32_t w, uint32_t h, const float* rgb, bool tonemap, bool exr, bool zip)
 {
     if (!path || !rgb || w == 0 || h == 0) return -1;
     Image img(w, h, tonemap, 1.0f);
     memcpy(img.getPixels(), rgb, (size_t)w * h * 3 * sizeof(float));
-    if (exr) img.saveExr(path);
+    if (exr) img.saveExr(path, zip);
     else img.savePpm(path);
     FILE* f = fopen(path, "rb");
     if (!f) return -1;
     fclose(f);
     return 0;
 }
-int prt_host_save_exr(const char* path, uint32_t w, uint32_t h, const float* rgb) { return saveImage(path, w, h, rgb, true, true); }
-int prt_host_save_ppm(const char* path, uint32_t w, uint32_t h, const float* rgb, int tonemap) { return saveImage(path, w, h, rgb, tonemap != 0, false); }
+int prt_host_save_exr(const char* path, uint32_t w, uint32_t h, const float* rgb, int zip) { return saveImage(path, w, h, rgb, true, true, zip != 0); }
+int prt_host_save_ppm(const char* path, uint32_t w, uint32_t h, const float* rgb, int tonemap) { return saveImage(path, w, h, rgb, tonemap != 0, false, false); }
 
 void prt_host_scene_bbox(const prt_host_scene* s, float lu[6])
 {

@@ -438,19 +438,10 @@ def test_png_bit_depths_interlace_and_colour_keys(L, tmp_path, interlace):
     assert np.array_equal(load("k16.png"), want)
 
 
-def test_exr_and_ppm_writers(L, tmp_path):
-    """Image::saveExr (image.cpp:82-139): half-float B, G, R planes -- written here as an uncompressed scan-line OpenEXR;
-    parsed back, every sample must be the round-to-nearest-even half of the float.  Image::savePpm (image.cpp:52-80)."""
+def _read_exr_halfs(raw, w, h):
+    """Parse a scan-line OpenEXR file with three HALF channels B, G, R (NO or ZIP compression): (h, 3, w) uint16 and the attributes."""
     import struct
-    rng = np.random.default_rng(9)
-    h, w = 7, 13
-    img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
-    specials = np.array([0.0, -0.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, 6.0975552e-5, 65504.0, 65519.9, 65520.0, 1e9, np.inf, -np.inf,
-                         np.nan, 1.0009765625, 1.00048828125, 1.00146484375, 0.33333334, -2.5, 1023.75, 2047.5, 2048.5], dtype=np.float32)
-    img.reshape(-1)[:len(specials)] = specials
-    p = tmp_path / "o.exr"
-    prt_amd.save_exr(str(p), img)
-    raw = open(p, "rb").read()
+    import zlib
     assert struct.unpack_from("<ii", raw, 0) == (20000630, 2)
     o, attrs = 8, {}
     while raw[o] != 0:
@@ -459,22 +450,62 @@ def test_exr_and_ppm_writers(L, tmp_path):
         (size,) = struct.unpack_from("<i", raw, o); o += 4
         attrs[name] = (typ, raw[o:o + size]); o += size
     o += 1
-    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"][1] == b"\0"
-    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1)
-    ch = attrs["channels"][1]
-    assert [ch[i * 18:i * 18 + 1] for i in range(3)] == [b"B", b"G", b"R"] and struct.unpack_from("<i", ch, 2)[0] == 1  # HALF
-    offs = struct.unpack_from(f"<{h}Q", raw, o)
+    comp = attrs["compression"][1][0]
+    lines = {0: 1, 3: 16}[comp]
+    blocks = (h + lines - 1) // lines
+    offs = struct.unpack_from(f"<{blocks}Q", raw, o)
+    out = np.zeros((h, 3, w), dtype=np.uint16)
+    for b in range(blocks):
+        yy, size = struct.unpack_from("<ii", raw, offs[b])
+        assert yy == b * lines
+        n_lines = min(lines, h - yy)
+        want = n_lines * w * 3 * 2
+        data = raw[offs[b] + 8: offs[b] + 8 + size]
+        if comp == 3 and size < want:
+            t = np.frombuffer(zlib.decompress(data), dtype=np.uint8).astype(np.int32)  # a real zlib stream
+            assert len(t) == want
+            t = (np.cumsum(np.concatenate([t[:1], t[1:] - 128])) & 255).astype(np.uint8)  # undo the delta predictor
+            half = (want + 1) // 2
+            data = np.empty(want, dtype=np.uint8)
+            data[0::2], data[1::2] = t[:half], t[half:]  # undo the even / odd byte split
+            data = data.tobytes()
+        assert len(data) == want
+        out[yy:yy + n_lines] = np.frombuffer(data, dtype="<u2").reshape(n_lines, 3, w)
+    return out, attrs
+
+
+def test_exr_and_ppm_writers(L, tmp_path):
+    """Image::saveExr (image.cpp:82-139): half-float B, G, R planes in a scan-line OpenEXR -- ZIP-compressed blocks of 16 lines
+    (tinyexr's default in the reference) or raw lines; parsed back (the ZIP blocks through Python's zlib), every sample must
+    be the round-to-nearest-even half of the float.  Image::savePpm (image.cpp:52-80)."""
+    import struct
+    rng = np.random.default_rng(9)
+    h, w = 37, 13  # three blocks of 16 lines, the last one short
+    img = (rng.random((h, w, 3), dtype=np.float32) * np.float32(4.0)).astype(np.float32)
+    img[8:30] = np.float32(0.5)  # smooth rows: blocks that really shrink
+    specials = np.array([0.0, -0.0, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 6.1e-5, 6.0975552e-5, 65504.0, 65519.9, 65520.0, 1e9, np.inf, -np.inf,
+                         np.nan, 1.0009765625, 1.00048828125, 1.00146484375, 0.33333334, -2.5, 1023.75, 2047.5, 2048.5], dtype=np.float32)
+    img.reshape(-1)[:len(specials)] = specials
     with np.errstate(over="ignore"):
         want = img.astype(np.float16)
-    for y in range(h):
-        yy, size = struct.unpack_from("<ii", raw, offs[y])
-        assert (yy, size) == (y, w * 3 * 2)
-        line = np.frombuffer(raw, dtype="<u2", count=w * 3, offset=offs[y] + 8).reshape(3, w)
-        for k, c in enumerate((2, 1, 0)):  # B, G, R
-            got, exp = line[k], want[y, :, c].view(np.uint16)
-            nan = np.isnan(want[y, :, c])
-            assert np.array_equal(got[~nan], exp[~nan]), (y, c)
-            assert ((got[nan] & 0x7c00) == 0x7c00).all() and ((got[nan] & 0x3ff) != 0).all()
+    sizes = {}
+    for zip_ in (True, False):
+        p = tmp_path / "o.exr"
+        prt_amd.save_exr(str(p), img, zip=zip_)
+        raw = open(p, "rb").read()
+        sizes[zip_] = len(raw)
+        halfs, attrs = _read_exr_halfs(raw, w, h)
+        assert attrs["compression"] == ("compression", b"\3" if zip_ else b"\0") and attrs["lineOrder"][1] == b"\0"
+        assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1)
+        ch = attrs["channels"][1]
+        assert [ch[i * 18:i * 18 + 1] for i in range(3)] == [b"B", b"G", b"R"] and struct.unpack_from("<i", ch, 2)[0] == 1  # HALF
+        for y in range(h):
+            for k, c in enumerate((2, 1, 0)):  # B, G, R
+                got, exp = halfs[y, k], want[y, :, c].view(np.uint16)
+                nan = np.isnan(want[y, :, c])
+                assert np.array_equal(got[~nan], exp[~nan]), (y, c)
+                assert ((got[nan] & 0x7c00) == 0x7c00).all() and ((got[nan] & 0x3ff) != 0).all()
+    assert sizes[True] < 0.8 * sizes[False]
     # PPM: c/(c+1), clamp, pow(1/2.2), * 255, truncate
     q = tmp_path / "o.ppm"
     fin = np.nan_to_num(img, nan=0.0, posinf=1e30, neginf=0.0)
