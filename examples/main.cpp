@@ -60,7 +60,7 @@ static void setupBunnyStandIn(Scene& scene, Camera& camera, float& exposure, uin
     m.calculateVertexNormals();
     m.calculateBounds();
     auto b = new Bvh;
-    b->build(std::move(m));
+    b->buildOnDevice(std::move(m)); // the same tree as Bvh::build, built on the GPU (prt_hip_build_bvh)
     scene.add(b);
     scene.setDirectionalLight(normalize(Vector3f(0.2f, 1.0f, 0.2f)), Vector3f(16.7f, 15.6f, 11.7f)); // main.cpp:84
     camera.create({0, 0.965, 2.6}, {0, 0, -1.0f}, width, height);

@@ -481,7 +481,425 @@ static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
     return true;
 }
 
-// Texture::load (texture.cpp:212-254) without stb_image: PNM, PNG or TGA by content.
+// JPEG (baseline and extended sequential DCT, Huffman coded, 8 bits; 1 or 3 components, any sampling factors, restart
+// intervals).  stb_image, which the reference decodes its textures with (texture.cpp:218-249), is not vendored; what follows
+// restates ITS published integer pipeline, because the texel values are part of the image: the 12-bit fixed-point
+// separable IDCT (constants x 4096, +512 >> 10 after the columns, +65536 + (128 << 17) >> 17 after the rows), chroma
+// upsampling by the (3 near + 1 far + 2) >> 2 and (9, 3, 3, 1) / 16 triangle filters, and YCbCr -> RGB in 20-bit fixed point
+// (1.40200, 0.71414, 0.34414 with its & 0xffff0000, 1.77200).  No stb_image is at hand to pin this against (DESIGN.md
+// "parity status"); progressive and arithmetic-coded files are refused.
+namespace {
+struct JpegHuff {
+    uint8_t size[257];
+    uint16_t code[257];
+    uint8_t values[256];
+    int maxcode[18], delta[17];
+    bool build(const int* counts)
+    {
+        int k = 0;
+        for (int i = 0; i < 16; i++)
+            for (int j = 0; j < counts[i]; j++) {
+                if (k >= 256) return false;
+                size[k++] = (uint8_t)(i + 1);
+            }
+        size[k] = 0;
+        int c = 0;
+        k = 0;
+        for (int j = 1; j <= 16; j++) {
+            delta[j] = k - c;
+            if (size[k] == j) {
+                while (size[k] == j) code[k++] = (uint16_t)(c++);
+                if (c - 1 >= (1 << j)) return false;
+            }
+            maxcode[j] = c << (16 - j);
+            c <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        return true;
+    }
+};
+struct JpegComp {
+    int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dcPred = 0;
+    int x = 0, y = 0, w2 = 0, h2 = 0;
+    std::vector<uint8_t> data;
+};
+struct JpegDec {
+    const uint8_t* p;
+    size_t n, pos = 0;
+    uint32_t codeBuffer = 0;
+    int codeBits = 0;
+    uint8_t marker = 0xff; // 0xff = none pending
+    bool nomore = false;
+    int get8() { return pos < n ? p[pos++] : 0; }
+    void grow()
+    {
+        do {
+            unsigned b = nomore ? 0 : (unsigned)get8();
+            if (b == 0xff) {
+                int c = get8();
+                while (c == 0xff) c = get8(); // fill bytes
+                if (c != 0) {
+                    marker = (uint8_t)c;
+                    nomore = true;
+                    return;
+                }
+            }
+            codeBuffer |= b << (24 - codeBits);
+            codeBits += 8;
+        } while (codeBits <= 24);
+    }
+    int decode(const JpegHuff& h)
+    {
+        if (codeBits < 16) grow();
+        const uint32_t temp = codeBuffer >> 16;
+        int k;
+        for (k = 1; k <= 16; k++)
+            if (temp < (uint32_t)h.maxcode[k]) break;
+        if (k == 17 || k > codeBits) return -1;
+        const int c = (int)((codeBuffer >> (32 - k)) & ((1u << k) - 1)) + h.delta[k];
+        if (c < 0 || c >= 256) return -1;
+        codeBits -= k;
+        codeBuffer <<= k;
+        return h.values[c];
+    }
+    int extend(int nbits) // receive + extend (ITU T.81 F.2.2.1)
+    {
+        if (nbits == 0) return 0;
+        if (codeBits < nbits) grow();
+        if (codeBits < nbits) return 0;
+        const int sgn = (int)(codeBuffer >> 31);
+        const uint32_t k = (codeBuffer >> (32 - nbits));
+        codeBuffer <<= nbits;
+        codeBits -= nbits;
+        return (int)k + (sgn ? 0 : (int)((~0u << nbits) + 1));
+    }
+};
+const uint8_t kJpegZigzag[64 + 15] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,
+                                      6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31,
+                                      39, 46, 53, 60, 61, 54, 47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+inline uint8_t jclamp(int x) { return (unsigned)x > 255u ? (x < 0 ? 0 : 255) : (uint8_t)x; }
+#define J_F2F(x) ((int)(((x) * 4096 + 0.5)))
+#define J_FSH(x) ((x) * 4096)
+#define J_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                               \
+    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                     \
+    p2 = s2; p3 = s6;                                                                           \
+    p1 = (p2 + p3) * J_F2F(0.5411961f);                                                         \
+    t2 = p1 + p3 * J_F2F(-1.847759065f);                                                        \
+    t3 = p1 + p2 * J_F2F(0.765366865f);                                                         \
+    p2 = s0; p3 = s4;                                                                           \
+    t0 = J_FSH(p2 + p3); t1 = J_FSH(p2 - p3);                                                   \
+    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                     \
+    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                         \
+    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                                     \
+    p5 = (p3 + p4) * J_F2F(1.175875602f);                                                       \
+    t0 = t0 * J_F2F(0.298631336f); t1 = t1 * J_F2F(2.053119869f);                               \
+    t2 = t2 * J_F2F(3.072711026f); t3 = t3 * J_F2F(1.501321110f);                               \
+    p1 = p5 + p1 * J_F2F(-0.899976223f); p2 = p5 + p2 * J_F2F(-2.562915447f);                   \
+    p3 = p3 * J_F2F(-1.961570560f); p4 = p4 * J_F2F(-0.390180644f);                             \
+    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+void jpegIdct(uint8_t* out, int stride, const short* data)
+{
+    int val[64], *v = val;
+    const short* d = data;
+    for (int i = 0; i < 8; ++i, ++d, ++v) {
+        if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
+            int dcterm = d[0] * 4;
+            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
+        } else {
+            J_IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
+            v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
+            v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+    }
+    v = val;
+    uint8_t* o = out;
+    for (int i = 0; i < 8; ++i, v += 8, o += stride) {
+        J_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
+        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+        o[0] = jclamp((x0 + t3) >> 17); o[7] = jclamp((x0 - t3) >> 17);
+        o[1] = jclamp((x1 + t2) >> 17); o[6] = jclamp((x1 - t2) >> 17);
+        o[2] = jclamp((x2 + t1) >> 17); o[5] = jclamp((x2 - t1) >> 17);
+        o[3] = jclamp((x3 + t0) >> 17); o[4] = jclamp((x3 - t0) >> 17);
+    }
+}
+// the four row resamplers: out has w * hs samples
+const uint8_t* jrow1(uint8_t*, const uint8_t* near, const uint8_t*, int, int) { return near; }
+const uint8_t* jrowV2(uint8_t* out, const uint8_t* near, const uint8_t* far, int w, int)
+{
+    for (int i = 0; i < w; ++i) out[i] = (uint8_t)((3 * near[i] + far[i] + 2) >> 2);
+    return out;
+}
+const uint8_t* jrowH2(uint8_t* out, const uint8_t* in, const uint8_t*, int w, int)
+{
+    if (w == 1) {
+        out[0] = out[1] = in[0];
+        return out;
+    }
+    out[0] = in[0];
+    out[1] = (uint8_t)((in[0] * 3 + in[1] + 2) >> 2);
+    int i;
+    for (i = 1; i < w - 1; ++i) {
+        int n = 3 * in[i] + 2;
+        out[i * 2 + 0] = (uint8_t)((n + in[i - 1]) >> 2);
+        out[i * 2 + 1] = (uint8_t)((n + in[i + 1]) >> 2);
+    }
+    out[i * 2 + 0] = (uint8_t)((in[w - 2] * 3 + in[w - 1] + 2) >> 2);
+    out[i * 2 + 1] = in[w - 1];
+    return out;
+}
+const uint8_t* jrowHV2(uint8_t* out, const uint8_t* near, const uint8_t* far, int w, int)
+{
+    if (w == 1) {
+        out[0] = out[1] = (uint8_t)((3 * near[0] + far[0] + 2) >> 2);
+        return out;
+    }
+    int t1 = 3 * near[0] + far[0], t0;
+    out[0] = (uint8_t)((t1 + 2) >> 2);
+    for (int i = 1; i < w; ++i) {
+        t0 = t1;
+        t1 = 3 * near[i] + far[i];
+        out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+        out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+    }
+    out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+    return out;
+}
+const uint8_t* jrowGeneric(uint8_t* out, const uint8_t* near, const uint8_t*, int w, int hs)
+{
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < hs; ++j) out[i * hs + j] = near[i];
+    return out;
+}
+} // namespace
+
+static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>& raw)
+{
+    std::vector<uint8_t> file;
+    uint8_t tmp[65536];
+    for (size_t n; (n = fread(tmp, 1, sizeof(tmp), f)) > 0;) file.insert(file.end(), tmp, tmp + n);
+    if (file.size() < 4 || file[0] != 0xff || file[1] != 0xd8) return false;
+    JpegDec d{file.data(), file.size()};
+    d.pos = 2;
+    uint16_t dequant[4][64];
+    JpegHuff hdc[4], hac[4];
+    bool haveDc[4] = {false, false, false, false}, haveAc[4] = {false, false, false, false};
+    JpegComp comp[3];
+    int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    bool sawFrame = false;
+    auto be16 = [&]() { int a = d.get8(); return (a << 8) | d.get8(); };
+    for (;;) {
+        int m = d.get8();
+        if (m != 0xff) return false;
+        while (m == 0xff) m = d.get8();
+        if (m == 0xd9) return false; // EOI before any scan
+        if (m == 0xdb) { // DQT
+            int L = be16() - 2;
+            while (L > 0) {
+                int q = d.get8(), prec = q >> 4, t = q & 15;
+                if (t > 3 || prec > 1) return false;
+                for (int i = 0; i < 64; i++) dequant[t][kJpegZigzag[i]] = (uint16_t)(prec ? be16() : d.get8());
+                L -= prec ? 129 : 65;
+            }
+            if (L != 0) return false;
+        } else if (m == 0xc4) { // DHT
+            int L = be16() - 2;
+            while (L > 0) {
+                int q = d.get8(), tc = q >> 4, th = q & 15, counts[16], total = 0;
+                if (tc > 1 || th > 3) return false;
+                for (int i = 0; i < 16; i++) total += counts[i] = d.get8();
+                if (total > 256) return false;
+                JpegHuff& hf = tc ? hac[th] : hdc[th];
+                if (!hf.build(counts)) return false;
+                for (int i = 0; i < total; i++) hf.values[i] = (uint8_t)d.get8();
+                (tc ? haveAc : haveDc)[th] = true;
+                L -= 17 + total;
+            }
+            if (L != 0) return false;
+        } else if (m == 0xdd) { // DRI
+            if (be16() != 4) return false;
+            restart = be16();
+        } else if (m == 0xc0 || m == 0xc1) { // SOF0 / SOF1
+            int L = be16();
+            if (d.get8() != 8) return false;
+            h = be16();
+            w = be16();
+            ncomp = d.get8();
+            if ((ncomp != 1 && ncomp != 3) || L != 8 + 3 * ncomp || w <= 0 || h <= 0) return false;
+            for (int i = 0; i < ncomp; i++) {
+                comp[i].id = d.get8();
+                int q = d.get8();
+                comp[i].h = q >> 4;
+                comp[i].v = q & 15;
+                comp[i].tq = d.get8();
+                if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4 || comp[i].tq > 3) return false;
+                hmax = std::max(hmax, comp[i].h);
+                vmax = std::max(vmax, comp[i].v);
+            }
+            for (int i = 0; i < ncomp; i++)
+                if (hmax % comp[i].h || vmax % comp[i].v) return false;
+            const int mcuw = hmax * 8, mcuh = vmax * 8, mcux = (w + mcuw - 1) / mcuw, mcuy = (h + mcuh - 1) / mcuh;
+            for (int i = 0; i < ncomp; i++) {
+                comp[i].x = (w * comp[i].h + hmax - 1) / hmax;
+                comp[i].y = (h * comp[i].v + vmax - 1) / vmax;
+                comp[i].w2 = mcux * comp[i].h * 8;
+                comp[i].h2 = mcuy * comp[i].v * 8;
+                comp[i].data.assign((size_t)comp[i].w2 * comp[i].h2, 0);
+            }
+            sawFrame = true;
+        } else if (m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            return false; // progressive, lossless, arithmetic: not decoded here
+        } else if (m == 0xda) { // SOS: the one interleaved scan of a baseline file (or one scan per component)
+            if (!sawFrame) return false;
+            int L = be16(), ns = d.get8();
+            if (ns < 1 || ns > ncomp || L != 6 + 2 * ns) return false;
+            int order[3];
+            for (int i = 0; i < ns; i++) {
+                int id = d.get8(), q = d.get8(), which = -1;
+                for (int k = 0; k < ncomp; k++)
+                    if (comp[k].id == id) which = k;
+                if (which < 0) return false;
+                comp[which].hd = q >> 4;
+                comp[which].ha = q & 15;
+                if (comp[which].hd > 3 || comp[which].ha > 3 || !haveDc[comp[which].hd] || !haveAc[comp[which].ha]) return false;
+                order[i] = which;
+            }
+            d.get8(); d.get8(); d.get8(); // spectral selection and approximation: fixed for sequential files
+            d.codeBuffer = 0; d.codeBits = 0; d.marker = 0xff; d.nomore = false;
+            for (int i = 0; i < ncomp; i++) comp[i].dcPred = 0;
+            int todo = restart ? restart : 0x7fffffff;
+            auto block = [&](JpegComp& c, uint8_t* out) -> bool {
+                short data[64];
+                memset(data, 0, sizeof(data));
+                if (d.codeBits < 16) d.grow();
+                int t = d.decode(hdc[c.hd]);
+                if (t < 0 || t > 15) return false;
+                int diff = t ? d.extend(t) : 0;
+                int dc = c.dcPred + diff;
+                c.dcPred = dc;
+                data[0] = (short)(dc * dequant[c.tq][0]);
+                int k = 1;
+                do {
+                    int rs = d.decode(hac[c.ha]);
+                    if (rs < 0) return false;
+                    int sz = rs & 15, r = rs >> 4;
+                    if (sz == 0) {
+                        if (rs != 0xf0) break; // end of block
+                        k += 16;
+                    } else {
+                        k += r;
+                        int zig = kJpegZigzag[k++];
+                        data[zig] = (short)(d.extend(sz) * dequant[c.tq][zig]);
+                    }
+                } while (k < 64);
+                jpegIdct(out, c.w2, data);
+                return true;
+            };
+            auto restartCheck = [&]() -> bool {
+                if (--todo > 0) return true;
+                if (d.codeBits < 24) d.grow();
+                if (!(d.marker >= 0xd0 && d.marker <= 0xd7)) return true; // no restart marker: the scan just goes on / ends
+                d.codeBuffer = 0; d.codeBits = 0; d.marker = 0xff; d.nomore = false;
+                for (int i = 0; i < ncomp; i++) comp[i].dcPred = 0;
+                todo = restart ? restart : 0x7fffffff;
+                return true;
+            };
+            if (ns == 1) { // non-interleaved: the component's own blocks, row by row
+                JpegComp& c = comp[order[0]];
+                const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+                for (int j = 0; j < bh; j++)
+                    for (int i = 0; i < bw; i++) {
+                        if (!block(c, &c.data[(size_t)c.w2 * j * 8 + i * 8])) return false;
+                        if (!restartCheck()) return false;
+                    }
+            } else {
+                const int mcux = (w + hmax * 8 - 1) / (hmax * 8), mcuy = (h + vmax * 8 - 1) / (vmax * 8);
+                for (int j = 0; j < mcuy; j++)
+                    for (int i = 0; i < mcux; i++) {
+                        for (int k = 0; k < ns; k++) {
+                            JpegComp& c = comp[order[k]];
+                            for (int y = 0; y < c.v; y++)
+                                for (int x = 0; x < c.h; x++)
+                                    if (!block(c, &c.data[(size_t)c.w2 * ((j * c.v + y) * 8) + (i * c.h + x) * 8])) return false;
+                        }
+                        if (!restartCheck()) return false;
+                    }
+            }
+            // what follows the entropy-coded data: EOI, or another scan of a non-interleaved file
+            if (d.marker == 0xff) {
+                while (d.pos < d.n) {
+                    int x = d.get8();
+                    if (x == 0xff) {
+                        int y = d.get8();
+                        while (y == 0xff) y = d.get8();
+                        if (y != 0) { d.marker = (uint8_t)y; break; }
+                    }
+                }
+            }
+            if (d.marker == 0xd9 || d.marker == 0xff) break;
+            d.pos -= 2; // step back onto the marker and parse on
+            d.marker = 0xff;
+        } else { // APPn, COM and the rest: skipped
+            int L = be16();
+            if (L < 2) return false;
+            d.pos += (size_t)(L - 2);
+        }
+        if (d.pos >= d.n) return false;
+    }
+    // ---- upsample and convert, one output row at a time
+    depth = ncomp == 1 ? 1 : 3;
+    raw.resize((size_t)w * h * depth);
+    struct Res {
+        const uint8_t* (*fn)(uint8_t*, const uint8_t*, const uint8_t*, int, int);
+        const uint8_t *line0, *line1;
+        int hs, vs, wLores, ystep, ypos;
+        std::vector<uint8_t> buf;
+    } res[3];
+    for (int k = 0; k < ncomp; k++) {
+        Res& r = res[k];
+        r.hs = hmax / comp[k].h;
+        r.vs = vmax / comp[k].v;
+        r.ystep = r.vs >> 1;
+        r.wLores = (w + r.hs - 1) / r.hs;
+        r.ypos = 0;
+        r.line0 = r.line1 = comp[k].data.data();
+        r.buf.resize((size_t)w + 3 + r.hs * 2);
+        r.fn = (r.hs == 1 && r.vs == 1) ? jrow1 : (r.hs == 1 && r.vs == 2) ? jrowV2 : (r.hs == 2 && r.vs == 1) ? jrowH2 : (r.hs == 2 && r.vs == 2) ? jrowHV2 : jrowGeneric;
+    }
+    for (int j = 0; j < h; j++) {
+        const uint8_t* co[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < ncomp; k++) {
+            Res& r = res[k];
+            const bool bot = r.ystep >= (r.vs >> 1);
+            co[k] = r.fn(r.buf.data(), bot ? r.line1 : r.line0, bot ? r.line0 : r.line1, r.wLores, r.hs);
+            if (++r.ystep >= r.vs) {
+                r.ystep = 0;
+                r.line0 = r.line1;
+                if (++r.ypos < comp[k].y) r.line1 += comp[k].w2;
+            }
+        }
+        uint8_t* out = &raw[(size_t)j * w * depth];
+        if (ncomp == 1) {
+            memcpy(out, co[0], (size_t)w);
+        } else {
+#define J_FIX(x) (((int)((x) * 4096.0f + 0.5f)) << 8)
+            for (int i = 0; i < w; i++) {
+                int yf = (co[0][i] << 20) + (1 << 19), cr = co[2][i] - 128, cb = co[1][i] - 128;
+                int r = yf + cr * J_FIX(1.40200f);
+                int g = yf + (cr * -J_FIX(0.71414f)) + ((cb * -J_FIX(0.34414f)) & 0xffff0000);
+                int b = yf + cb * J_FIX(1.77200f);
+                out[3 * i + 0] = jclamp(r >> 20);
+                out[3 * i + 1] = jclamp(g >> 20);
+                out[3 * i + 2] = jclamp(b >> 20);
+            }
+        }
+    }
+    return true;
+}
+
+// Texture::load (texture.cpp:212-254) without stb_image: PNM, PNG, JPEG or TGA by content.
 bool loadTexture(const std::string& path, Texture& tex, bool bump)
 {
     FILE* f = fopen(path.c_str(), "rb");
@@ -490,7 +908,8 @@ bool loadTexture(const std::string& path, Texture& tex, bool bump)
     std::vector<uint8_t> raw;
     int c0 = fgetc(f);
     ungetc(c0, f);
-    bool ok = (c0 == 'P') ? decodePnm(f, w, h, depth, raw) : (c0 == 0x89) ? decodePng(f, w, h, depth, raw) : decodeTga(f, w, h, depth, raw);
+    bool ok = (c0 == 'P') ? decodePnm(f, w, h, depth, raw) : (c0 == 0x89) ? decodePng(f, w, h, depth, raw) : (c0 == 0xff) ? decodeJpeg(f, w, h, depth, raw)
+                                                                                                               : decodeTga(f, w, h, depth, raw);
     fclose(f);
     if (!ok || w > 65535 || h > 65535) return false;
     // texture.cpp:226-247: grey stays 1 component, everything else becomes RGBA; 3-component bump maps become
@@ -557,7 +976,7 @@ void parseMtl(const std::string& path, const std::string& dir, const std::vector
             bool bump = key != "map_Kd";
             Texture& t = bump ? cur->bumpMap : cur->diffuseMap;
             if (!loadTexture(dir + "/" + name, t, bump))
-                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM, 8-bit PNG and TGA only: stb is not vendored)\n", name.c_str());
+                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM, PNG, sequential JPEG and TGA are read here: stb is not vendored)\n", name.c_str());
         }
     }
     for (auto& m : mats) m.alphaTest = m.diffuseMap.isAlphaTestRequired(); // material.cpp:79

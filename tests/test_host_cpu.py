@@ -438,6 +438,147 @@ def test_png_bit_depths_interlace_and_colour_keys(L, tmp_path, interlace):
     assert np.array_equal(load("k16.png"), want)
 
 
+_ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50,
+       43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _jpeg(path, planes, sampling, q=2, restart=0):
+    """A baseline (SOF0) JPEG writer for the tests: planes = list of 2-D uint8 arrays at FULL resolution (Y or Y, Cb, Cr);
+    sampling = [(h, v), ...]; chroma planes are box-filtered down.  Own Huffman tables (every code 4 bits for the 12 DC
+    categories, 8 bits for the 162 AC symbols) and a flat quantiser q.  Returns the planes the decoder should reconstruct
+    BEFORE upsampling (i.e. after subsampling + quantisation round trip is not modelled: the test compares with a tolerance)."""
+    import struct
+    from scipy.fft import dctn
+    H, W = planes[0].shape
+    hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+    mcuw, mcuh = 8 * hmax, 8 * vmax
+    mx, my = (W + mcuw - 1) // mcuw, (H + mcuh - 1) // mcuh
+    comps = []
+    for p, (sh, sv) in zip(planes, sampling):
+        fx, fy = hmax // sh, vmax // sv
+        pad = np.pad(p.astype(np.float64), ((0, my * mcuh - H), (0, mx * mcuw - W)), mode="edge")
+        sub = pad.reshape(pad.shape[0] // fy, fy, pad.shape[1] // fx, fx).mean(axis=(1, 3))
+        comps.append(sub)
+    ac_syms = [0x00, 0xf0] + [(r << 4) | z for r in range(16) for z in range(1, 11)]
+    dc_code = {c: (c, 4) for c in range(12)}
+    ac_code = {sym: (i, 8) for i, sym in enumerate(ac_syms)}
+    bits = []
+
+    def put(v, n):
+        for k in range(n - 1, -1, -1):
+            bits.append((v >> k) & 1)
+
+    def cat(v):
+        a = abs(int(v))
+        return a.bit_length()
+
+    def put_val(v, n):
+        v = int(v)
+        put(v if v >= 0 else v + (1 << n) - 1, n)
+
+    pred = [0] * len(comps)
+    out_bytes = bytearray()
+
+    def flush_bits():
+        while len(bits) % 8:
+            bits.append(1)
+        for i in range(0, len(bits), 8):
+            b = 0
+            for k in range(8):
+                b = (b << 1) | bits[i + k]
+            out_bytes.append(b)
+            if b == 0xff:
+                out_bytes.append(0)
+        bits.clear()
+
+    def encode_block(ci, blk):
+        co = np.round(dctn(blk - 128.0, norm="ortho") / q).astype(np.int64).reshape(-1)
+        zz = [int(co[k]) for k in _ZZ]
+        diff = zz[0] - pred[ci]
+        pred[ci] = zz[0]
+        n = cat(diff)
+        put(*dc_code[n])
+        if n:
+            put_val(diff, n)
+        run = 0
+        last = max([k for k in range(1, 64) if zz[k]] + [0])
+        for k in range(1, last + 1):
+            if zz[k] == 0:
+                run += 1
+                continue
+            while run > 15:
+                put(*ac_code[0xf0])
+                run -= 16
+            n = cat(zz[k])
+            put(*ac_code[(run << 4) | n])
+            put_val(zz[k], n)
+            run = 0
+        if last < 63:
+            put(*ac_code[0x00])
+
+    count = 0
+    rst = 0
+    for j in range(my):
+        for i in range(mx):
+            for ci, (sh, sv) in enumerate(sampling):
+                for y in range(sv):
+                    for x in range(sh):
+                        by, bx = (j * sv + y) * 8, (i * sh + x) * 8
+                        encode_block(ci, comps[ci][by:by + 8, bx:bx + 8])
+            count += 1
+            if restart and count % restart == 0 and not (j == my - 1 and i == mx - 1):
+                flush_bits()
+                out_bytes += bytes([0xff, 0xd0 + rst])
+                rst = (rst + 1) & 7
+                pred = [0] * len(comps)
+    flush_bits()
+
+    def seg(marker, data):
+        return bytes([0xff, marker]) + struct.pack(">H", len(data) + 2) + data
+    with open(path, "wb") as f:
+        f.write(b"\xff\xd8")
+        f.write(seg(0xdb, bytes([0]) + bytes([q] * 64)))
+        f.write(seg(0xc0, struct.pack(">BHHB", 8, H, W, len(comps)) + b"".join(bytes([k + 1, (sh << 4) | sv, 0]) for k, (sh, sv) in enumerate(sampling))))
+        f.write(seg(0xc4, bytes([0x00] + [0, 0, 0, 12] + [0] * 12 + list(range(12)))))
+        f.write(seg(0xc4, bytes([0x10] + [0] * 7 + [162] + [0] * 8 + ac_syms)))
+        if restart:
+            f.write(seg(0xdd, struct.pack(">H", restart)))
+        f.write(seg(0xda, bytes([len(comps)]) + b"".join(bytes([k + 1, 0x00]) for k in range(len(comps))) + bytes([0, 63, 0])))
+        f.write(bytes(out_bytes) + b"\xff\xd9")
+
+
+@pytest.mark.parametrize("sampling,restart", [([(1, 1)], 0), ([(1, 1), (1, 1), (1, 1)], 0), ([(2, 2), (1, 1), (1, 1)], 3), ([(2, 1), (1, 1), (1, 1)], 0),
+                                              ([(1, 2), (1, 1), (1, 1)], 5)])
+def test_obj_mtl_reader_decodes_jpeg_maps(L, tmp_path, sampling, restart):
+    """Sequential JPEG textures (the format of Sponza's and San Miguel's maps; texture.cpp:218-249 reads them through
+    stb_image): grey and YCbCr files with 4:4:4, 4:2:0, 4:2:2 and 4:4:0 sampling and restart intervals come back within the
+    quantisation and chroma-filter error of the image that was encoded, grey as one channel, colour as RGBA with alpha 255."""
+    rng = np.random.default_rng(21)
+    H, W = 37, 45  # ragged against every MCU size
+    yy, xx = np.mgrid[0:H, 0:W]
+    smooth = lambda a, b, c: (127 + 90 * np.sin(xx / a + c) * np.cos(yy / b)).clip(0, 255)  # noqa: E731
+    Y = smooth(7.0, 5.0, 0.3)
+    Y[10:20, 12:30] = 230  # an edge
+    planes = [Y] if len(sampling) == 1 else [Y, smooth(15.0, 11.0, 1.0), smooth(13.0, 17.0, 2.0)]
+    planes = [np.round(p).astype(np.uint8) for p in planes]
+    _jpeg(tmp_path / "t.jpg", planes, sampling, q=2, restart=restart)
+    (tmp_path / "n.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd t.jpg\n")
+    (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    sc = prt_amd.Scene()
+    sc.add(prt_amd.Mesh.load_obj(str(tmp_path / "n.obj")))
+    tex = sc.arrays()["textures"][0].astype(np.int32)
+    if len(sampling) == 1:
+        assert tex.shape == (H, W, 1)
+        assert np.abs(tex[..., 0] - planes[0]).max() <= 4
+        return
+    assert tex.shape == (H, W, 4) and (tex[..., 3] == 255).all()
+    y, cb, cr = (p.astype(np.float64) for p in planes)
+    want = np.stack([y + 1.402 * (cr - 128), y - 0.344136 * (cb - 128) - 0.714136 * (cr - 128), y + 1.772 * (cb - 128)], -1).clip(0, 255)
+    err = np.abs(tex[..., :3] - want)
+    sub = sampling[0] != (1, 1)
+    assert err.mean() < (2.5 if sub else 1.5) and np.percentile(err, 99) <= (12 if sub else 6), (err.mean(), err.max())
+
+
 def _read_exr_halfs(raw, w, h):
     """Parse a scan-line OpenEXR file with three HALF channels B, G, R (NO or ZIP compression): (h, 3, w) uint16 and the attributes."""
     import struct
