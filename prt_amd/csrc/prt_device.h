@@ -12,9 +12,11 @@
 #include "prt_devmath.h"
 
 #define PRT_MAX_BVH 8
-#define PRT_STACK_LDS 16     // stack entries per lane kept in LDS (4 B each)
+#ifndef PRT_STACK_LDS
+#define PRT_STACK_LDS 12     // stack entries per lane kept in LDS (4 B each); 12 + the 4 KB of hot records let 8 blocks share a CU's LDS
+#endif
 #ifndef PRT_STACK_LDS_PACKET
-#define PRT_STACK_LDS_PACKET 8 // the same for the packet traversal (8 B each: reference + entry distance)
+#define PRT_STACK_LDS_PACKET (PRT_STACK_LDS / 2) // the same for the packet traversal (8 B each: reference + entry distance)
 #endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #ifndef PRT_BLOCK
@@ -406,7 +408,9 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
 // ds_read_b128 instead of sending four more gathers down the texture-address path, the busiest unit of these kernels
 // (profiles/: TA busy 76 % of the frame); other kernels read the same copy from DevScene::hotNodes.
 #define PRT_REF_HOT 0x40000000u
-#define PRT_HOT_NODES 64
+#ifndef PRT_HOT_NODES
+#define PRT_HOT_NODES 64 // a power of two
+#endif
 
 // Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper
 // ones in a per-thread global spill area.  `t` (the box entry distance) is only stored by the packet traversal.
@@ -415,7 +419,7 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) prt_f4 lds_f4;
-template <int NLDS> // stack entries kept in LDS; deeper ones spill (NLDS a power of two)
+template <int NLDS> // stack entries kept in LDS; deeper ones spill
 struct StackT {
     lds_u32* ldsRef; // &refs[threadIdx.x]
     lds_f32* ldsT;   // &ts[threadIdx.x]
@@ -429,7 +433,7 @@ struct StackT {
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
-        uint32_t v = ldsRef[(e & (NLDS - 1)) * PRT_BLOCK];
+        uint32_t v = ldsRef[(e < NLDS ? e : 0) * PRT_BLOCK];
         if (e >= NLDS) v = gld(&spill[(size_t)(2 * (e - NLDS)) * spillStride]);
         return v;
     }
@@ -445,7 +449,7 @@ struct StackT {
     }
     __device__ __forceinline__ float getT(int e) const
     {
-        float v = ldsT[(e & (NLDS - 1)) * PRT_BLOCK];
+        float v = ldsT[(e < NLDS ? e : 0) * PRT_BLOCK];
         if (e >= NLDS) v = asf(gld(&spill[(size_t)(2 * (e - NLDS) + 1) * spillStride]));
         return v;
     }

@@ -27,10 +27,13 @@
 #define PRT_POOL_CHUNKS 4 // rows of 64 pixel groups a block keeps in flight
 #endif
 #ifndef PRT_FRAME_WAVES
-#define PRT_FRAME_WAVES 7 // waves per SIMD the frame kernel is compiled for
+#define PRT_FRAME_WAVES 8 // waves per SIMD the frame kernel is compiled for: 64 VGPRs, 80 SGPRs, 8 blocks of 256 per CU (18.7 KB of LDS each)
 #endif
 #ifndef PRT_SHADE_MIN
-#define PRT_SHADE_MIN 16u // ready groups that make a wave at a decision point take the shade role
+#define PRT_SHADE_MIN 48u // ready groups that make a wave at a decision point take the shade role
+#endif
+#ifndef PRT_HOT_LDS
+#define PRT_HOT_LDS 1 // keep the PRT_HOT_NODES records nearest the roots in LDS (4 KB per block)
 #endif
 #ifndef PRT_TRACE_PRIO
 #define PRT_TRACE_PRIO 1
@@ -39,7 +42,7 @@
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
 #ifndef PRT_DRAIN_READY
-#define PRT_DRAIN_READY 192u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
+#define PRT_DRAIN_READY 256u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
 #endif
 #ifndef PRT_SHADE_INLINE
 #define PRT_SHADE_INLINE __noinline__
@@ -97,7 +100,7 @@ struct FrameArgs {
 struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
     uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
-    float hot[PRT_HOT_NODES * 16]; // DevScene::hotNodes (16-byte aligned: read with ds_read_b128)
+    float hot[PRT_HOT_LDS ? PRT_HOT_NODES * 16 : 4]; // DevScene::hotNodes (16-byte aligned: read with ds_read_b128)
     uint32_t pending[PRT_POOL_GROUPS];
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
@@ -581,7 +584,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const uint32_t slotBase = blockIdx.x * PRT_POOL_SLOTS;
     const uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid),
-                          A.spillStride, (const lds_f4*)&B->hot[0]};
+                          A.spillStride, PRT_HOT_LDS ? (const lds_f4*)&B->hot[0] : nullptr};
     const DevScene& sc = A.sc;
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
     const BlockLds B = block_lds();
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     for (uint32_t i = tid; i < PRT_POOL_GROUPS; i += PRT_BLOCK) B->pending[i] = PEND_DONE;
-    for (uint32_t i = tid; i < PRT_HOT_NODES * 4u; i += PRT_BLOCK) {
+    for (uint32_t i = tid; i < (PRT_HOT_LDS ? PRT_HOT_NODES * 4u : 0u); i += PRT_BLOCK) {
         const float4 v = gld4(A.sc.hotNodes + i);
         B->hot[4 * i] = v.x;
         B->hot[4 * i + 1] = v.y;
