@@ -163,10 +163,10 @@ int prt_hip_build_bvh(prt_hip_ctx* ctx, uint32_t primCount, const uint32_t* indi
 /* ---- the hot path: replaces PathTracer::TraceBlock (path_tracer.cpp:17-33; pixel rectangle
  * INCLUSIVE as there) + Image::writePixel (image.cpp:44-50).  d_rgb is a DEVICE pointer to
  * width*height*3 floats (pixel (x,y) at (x + y*width)*3), or NULL for the context's own
- * framebuffer.  stream is a hipStream_t (NULL = the context's stream): the render is ordered after
- * the work already queued on it and before what is queued on it next (the kernels themselves run on
- * the context's own streams).  Asynchronous with respect to the host; prt_hip_download /
- * prt_hip_get_stats synchronise. ---- */
+ * framebuffer.  stream is a hipStream_t (NULL = the context's stream): the render -- ONE persistent
+ * kernel launch for the whole rectangle, whatever its size -- is ordered after the work already queued
+ * on it and before what is queued on it next.  Asynchronous with respect to the host;
+ * prt_hip_download / prt_hip_get_stats synchronise. ---- */
 int prt_hip_render(prt_hip_ctx* ctx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                    const prt_render_params* params, float* d_rgb, void* stream);
 /* GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): one jittered camera ray per pixel, the surface's diffuse colour

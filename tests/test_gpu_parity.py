@@ -816,6 +816,23 @@ def test_cpp_driver_two_scenes_from_one_stack_slot(tracer, tmp_path):
     assert a.tobytes() != b.tobytes()
 
 
+def test_cpp_multi_process_example_one_rank(tmp_path):
+    """examples/prt_mp.cpp -- a C++ host with one process per GPU: forked ranks, the communicator id over pipes,
+    prt_hip_comm_init / prt_hip_render(rank, nranks) / prt_hip_gather_rccl, and rank 0 requiring the gathered image to equal
+    its own one-GPU render.  This box has one GPU and RCCL takes one rank per device, so the run is the 1-rank case (a real
+    communicator, the library's pack / de-interleave path); asking for 2 ranks must be refused with a message, not hang."""
+    import subprocess
+    ex = os.path.join(T.ROOT, "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    out = subprocess.run([os.path.join(ex, "prt_mp"), "1", "cornell", "160", "96", "16"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "EQUALS the one-GPU image" in out.stdout, out.stdout
+    assert (tmp_path / "prt_mp.exr").stat().st_size > 0
+    if prt_amd.device_count() < 2:
+        out = subprocess.run([os.path.join(ex, "prt_mp"), "2", "cornell", "64", "64", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 3 and "need 2 devices" in out.stderr, out.stdout + out.stderr
+
+
 def test_gbuffer_visualizer_matches_reference_and_oracle(tracer, c1):
     """GbufferVisualizer (gbuffer_visualizer.cpp:17-51) on the traversal kernels' wave loop: Cornell + teapot
     against the compiled reference's images (tests/golden/gbuffer.npz), the textured atrium against the oracle."""
