@@ -286,11 +286,12 @@ def main():
                          "traffic": traffic_rate, "hbm_frac": (traffic_rate / HBM_PEAK_GBS) if traffic_rate else None,
                          "traffic_bytes_per_launch": traffic_bytes, "traffic_source": ev["file"] if ev else None,
                          "traffic_source_sha16": ev["source_sha16"] if ev else None, "source_sha16": prt_amd.source_sha16(),
-                         "limiter": ("vector-memory gather path and dependent L2 round trips, not DRAM bytes: texture-address units busy "
-                                     f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f} of the frame, waves waiting "
-                                     f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, "
+                         "limiter": ("latency of dependent record gathers at 8 waves per SIMD, not DRAM bytes and not instruction issue: waves wait "
+                                     f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, the gather path is busy "
+                                     f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f} of the frame, "
                                      f"L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit {ev['derived']['l2_hit_rate']:.2f}, "
-                                     f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction") if ev
+                                     f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction; "
+                                     "+22 % vector instructions cost +4 % time (DESIGN.md 4.3)") if ev
                          else "see profiles/ (no counter summary taken with these kernel sources)",
                          "kernel": "frame_kernel: one persistent launch per frame (shade passes + four ray traversals as roles of its waves)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(B),

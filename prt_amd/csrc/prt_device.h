@@ -174,6 +174,11 @@ struct DevHit {
 struct Traffic {
     unsigned long long nBox, nTri; // a persistent trace lane can exceed 2^32
     uint32_t nHit, nTap;
+#ifdef PRT_PROFILE
+    // tallies of the profile build: rounds of either kind and the lanes that took part in them (wave-uniform); stack pops
+    // and those that came from the spill area in HBM (per lane)
+    unsigned long long pNodeRounds, pNodeLanes, pLeafRounds, pLeafLanes, pTri2Lanes, pPops, pDeepPops;
+#endif
 };
 
 // ray.h:26-40: swap axis from the SIGNED components (Vector3f::GetLongestElement, vecmath.h:216)
@@ -421,6 +426,7 @@ typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) prt_f4 lds_f4;
 template <int NLDS> // stack entries kept in LDS; deeper ones spill
 struct StackT {
+    static constexpr int kLds = NLDS;
     lds_u32* ldsRef; // &refs[threadIdx.x]
     lds_f32* ldsT;   // &ts[threadIdx.x]
     uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
@@ -587,11 +593,12 @@ __device__ __forceinline__ uint32_t tracer_pop(Tracer& T, const STK& st, Traffic
             if (st.getT(T.sp) < T.hit.t) return st.get(T.sp); // the pop-time test of the reference
         }
         return PRT_REF_NONE;
-    } else if (MODE == PRT_MODE_SINGLE) {
-        if (T.sp == 0) return PRT_REF_NONE;
-        return st.get(--T.sp);
     } else {
         if (T.sp == 0) return PRT_REF_NONE;
+#ifdef PRT_PROFILE
+        tr.pPops++;
+        if (T.sp - 1 >= STK::kLds) tr.pDeepPops++;
+#endif
         return st.get(--T.sp);
     }
 }
@@ -796,6 +803,24 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
         const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0u) break;
         const bool doNode = nNode >= nLeaf; // weighting either side, or staying with one kind while it has 16-32 lanes, measured slower
+#ifdef PRT_PAD_VALU
+        { // sensitivity probe of tools/build_variants.py: PRT_PAD_VALU extra vector instructions per round (never in the product)
+            float pad = T.maxT;
+#pragma unroll
+            for (int q = 0; q < PRT_PAD_VALU; q++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
+            asm volatile("" ::"v"(pad));
+        }
+#endif
+#ifdef PRT_PROFILE
+        if (doNode) {
+            tr.pNodeRounds++;
+            tr.pNodeLanes += nNode;
+        } else {
+            tr.pLeafRounds++;
+            tr.pLeafLanes += nLeaf;
+            tr.pTri2Lanes += (unsigned long long)__popcll(__ballot(onLeaf && (T.ref & 15u) > 1u));
+        }
+#endif
         if (doNode) {
             if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
         } else {

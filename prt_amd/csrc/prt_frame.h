@@ -214,7 +214,7 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
     const BlockLds B = block_lds();
     uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     WaveStats ws{0, 0, 0};
-    Traffic tr{0, 0, 0, 0};
+    Traffic tr{};
     const uint32_t lane = threadIdx.x & 63u, slot = lane & 7u, gbase = lane & ~7u;
     const bool inRange = P != PRT_NONE;
     const uint32_t g = inRange ? P : 0u;
@@ -589,7 +589,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);
     const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
-    Traffic tr{0, 0, 0, 0};
+    Traffic tr{};
     uint32_t overflow = 0;
     Tracer T;
     T.ref = PRT_REF_NONE;
@@ -604,7 +604,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     for (uint32_t j = 0; j < PRT_CLAIM / 64u; j++) held[j] = 0;
     __builtin_amdgcn_s_setprio(PRT_TRACE_PRIO); // tracing waves sit on dependent loads: they issue first, shading fills in
 #ifdef PRT_PROFILE
-    unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pT0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pRefills = 0, pRefillLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
         // ---- 1. finished rays of the previous turn: their stores are complete -> tell the group
@@ -679,6 +679,10 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
 #ifdef PRT_PROFILE
             pClaims++;
             if (!__any(gotRay)) pEmptyClaims++;
+            else {
+                pRefills++;
+                pRefillLanes += (unsigned long long)__popcll(__ballot(!active && gotRay));
+            }
 #endif
             if (!active && gotRay) {
                 owner = bits & 0x3ffffffu;
@@ -761,8 +765,25 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef PRT_PROFILE
+    unsigned long long pops = tr.pPops, deepPops = tr.pDeepPops; // per lane: summed over the wave by all its lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        pops += (unsigned long long)__shfl_xor((long long)pops, o, 64);
+        deepPops += (unsigned long long)__shfl_xor((long long)deepPops, o, 64);
+    }
     if (lane == 0) {
         unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+        if (MODE != PRT_MODE_PACKET) { // (the packet traversal pops in a loop of its own and is not counted; word 39 is its slot)
+            atomicAdd(&C[39 + MODE * 8], pops);
+            atomicAdd(&C[39], deepPops);
+        }
+        atomicAdd(&C[32 + MODE * 8], tr.pNodeRounds);
+        atomicAdd(&C[33 + MODE * 8], tr.pNodeLanes);
+        atomicAdd(&C[34 + MODE * 8], tr.pLeafRounds);
+        atomicAdd(&C[35 + MODE * 8], tr.pLeafLanes);
+        atomicAdd(&C[36 + MODE * 8], tr.pTri2Lanes);
+        atomicAdd(&C[37 + MODE * 8], pRefillLanes);
+        atomicAdd(&C[38 + MODE * 8], pRefills);
         atomicAdd(&C[16 + MODE * 3], pTurns);
         atomicAdd(&C[17 + MODE * 3], pLanes);
         atomicAdd(&C[18 + MODE * 3], (__builtin_amdgcn_s_memtime() - pT0) >> 10);

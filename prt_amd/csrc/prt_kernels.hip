@@ -182,7 +182,7 @@ struct GbufSrc {
         const uint32_t x = A->x0 + i % A->rw, y = A->y0 + i / A->rw;
         Vec3 color = mk3(0.0f, 0.0f, 0.0f);
         if (h.t != -1.0f) {
-            Traffic tr{0, 0, 0, 0};
+            Traffic tr{};
             Surface s;
             get_surface<false>(A->sc, h, s, tr);
             if (A->type == 0u) color = sample_diffuse<false>(A->sc, s.mat, s.uv, tr);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
     const uint32_t tid = threadIdx.x;
     const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
     GbufSrc src{&A};
-    Traffic tr{0, 0, 0, 0};
+    Traffic tr{};
     uint32_t overflow = 0;
     trace_loop<PRT_MODE_SINGLE, false>(A.sc, src, st, tr, overflow);
     if (overflow) atomicAdd(&A.counters[7], 1ull);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
     const uint32_t tid = threadIdx.x;
     const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
     ArraySrc src{&A, MODE};
-    Traffic tr{0, 0, 0, 0};
+    Traffic tr{};
     uint32_t overflow = 0;
     trace_loop<MODE, false>(A.sc, src, st, tr, overflow);
     if (overflow) atomicAdd(&A.counters[7], 1ull);
@@ -1031,6 +1031,13 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
             fprintf(stderr, "  trace mode %d: %.1f M loop turns, %.1f lanes with a ray per turn, %.1f Gcycles in the loops => %.0f cycles per turn\n", m, h[16 + 3 * m] / 1e6,
                     (double)h[17 + 3 * m] / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1), h[18 + 3 * m] * 1024.0 / 1e9,
                     h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
+        for (int m = 0; m < 4; m++) {
+            const unsigned long long* q = h + 32 + 8 * m;
+            fprintf(stderr, "  mode %d rounds: node %.1f M with %.1f lanes, leaf %.1f M with %.1f lanes (%.1f on a second triangle); refills %.1f M with %.1f lanes\n", m,
+                    q[0] / 1e6, (double)q[1] / (double)(q[0] ? q[0] : 1), q[2] / 1e6, (double)q[3] / (double)(q[2] ? q[2] : 1),
+                    (double)q[4] / (double)(q[2] ? q[2] : 1), q[6] / 1e6, (double)q[5] / (double)(q[6] ? q[6] : 1));
+        }
+        fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));
     }
 #endif

@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import prt_amd
+if os.environ.get("PRT_LIB"):
+    prt_amd.LIB_PATH = os.environ["PRT_LIB"]  # a tuning variant instead of the product library
 W, H, spp, depth = 1920, 1080, 64, 8
 scene, camera, exposure = prt_amd.setup_atrium_standin(W, H, tris=262000, seed=1)
 tr = prt_amd.PathTracer(device=0, max_depth=depth, seed=12345)

@@ -21,6 +21,9 @@ if len(sys.argv) > 1:
     print(f"{os.path.basename(sys.argv[1])} {os.environ.get('PRT_FRAME_BPC', '')}: {min(ms):.1f} ms  ({st['raysTraced'] / min(ms) / 1e3:.0f} Mray/s); 1/8 share {min(share):.1f} ms", flush=True)
     tr.close()
 else:
+    # every library several times, interleaved (one child process per run): frame times wander by 2-3 % between processes
     var = os.path.join(root, "prt_amd", "lib", "var")
-    for f in sorted(os.listdir(var)):
-        subprocess.call([sys.executable, os.path.abspath(__file__), os.path.join(var, f)])
+    rounds = int(os.environ.get("PRT_BENCH_ROUNDS", "3"))
+    for r in range(rounds):
+        for f in sorted(os.listdir(var)):
+            subprocess.call([sys.executable, os.path.abspath(__file__), os.path.join(var, f)])
