@@ -44,7 +44,8 @@ void prt_host_scene_destroy(prt_host_scene* s);
 int prt_host_scene_add_mesh(prt_host_scene* s, prt_host_mesh* m);
 void prt_host_scene_set_directional_light(prt_host_scene* s, const float dir[3], const float intensity[3]); /* scene.h:30-35 */
 /* Scene::setInfiniteAreaLight (scene.h:42-45) -> InfiniteAreaLight::create (light.cpp:30-84): from float RGBA texels (row 0 first),
- * or from an RGB PFM file (the reference reads an .exr through tinyexr); 0 or -1 when the file cannot be used */
+ * or from a file: OpenEXR as the reference reads it through tinyexr (scan lines; NO / RLE / ZIPS / ZIP blocks) or an RGB PFM; 0, or -1 when
+ * the file cannot be used */
 void prt_host_scene_set_env_light(prt_host_scene* s, int32_t width, int32_t height, const float* rgba);
 int prt_host_scene_load_env_light(prt_host_scene* s, const char* path);
 /* the descriptor of the scene as it stands; valid until the scene is changed or destroyed */

@@ -302,7 +302,7 @@ class Scene:
         lib().prt_host_scene_set_directional_light(self._h, _f3(direction), _f3(intensity))
 
     def set_infinite_area_light(self, env):
-        """Scene::setInfiniteAreaLight (scene.h:42-45): `env` is a path to an RGB PFM file or a float array (h, w, 4) RGBA, row 0 = top."""
+        """Scene::setInfiniteAreaLight (scene.h:42-45): `env` is a path to an OpenEXR file (scan lines; NO / RLE / ZIPS / ZIP) or an RGB PFM file, or a float array (h, w, 4) RGBA, row 0 = top."""
         if isinstance(env, (str, bytes, os.PathLike)):
             _check(lib().prt_host_scene_load_env_light(self._h, os.fsencode(env)), "prt_host_scene_load_env_light")
             return

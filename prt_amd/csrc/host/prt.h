@@ -183,7 +183,7 @@ class InfiniteAreaLight
 {
 public:
     void init();
-    void create(const char* path); // a PFM file here (light.cpp:32 reads an .exr through tinyexr)
+    void create(const char* path); // light.cpp:32: an .exr (own reader: scan lines, NO / RLE / ZIPS / ZIP), or a PFM
     void create(int32_t width, int32_t height, const float* rgba); // light.cpp:34-84 on texels already in memory
     void release();
     bool isValid() const { return !m_texels.empty(); }

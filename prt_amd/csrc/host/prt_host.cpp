@@ -179,8 +179,176 @@ void InfiniteAreaLight::release()
     m_width = m_height = 0;
 }
 
-// The reference decodes an OpenEXR file (texture.cpp:256-310, tinyexr).  This build reads a PFM ("PF", width height, scale;
-// rows bottom to top, RGB float32; a negative scale means little-endian) into the same RGBA float layout, row 0 = top.
+// ---- OpenEXR input (texture.cpp:256-310 decodes the environment map with tinyexr's LoadEXR: RGBA float32, rows top to bottom).
+// tinyexr is absent here, so the format is read directly: single-part scan-line files with NO, RLE, ZIPS or ZIP compression
+// and UINT / HALF / FLOAT channels sampled 1:1.  Channels R, G, B (and A) by name; a file with one channel is grey, a missing A
+// is 1, as LoadEXR fills them.  PIZ / PXR24 / B44 / DWA, tiles, deep and multi-part files are refused with a message.
+bool inflateZlibBytes(const std::vector<uint8_t>& in, std::vector<uint8_t>& out); // prt_models.cpp (the PNG reader's inflate)
+
+static float halfToFloat(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, exp = (h >> 10) & 31u, man = h & 1023u;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) {
+            u = sign;
+        } else { // subnormal half: normalise
+            int e = -1;
+            uint32_t m = man;
+            do {
+                e++;
+                m <<= 1;
+            } while (!(m & 1024u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 1023u) << 13);
+        }
+    } else if (exp == 31) {
+        u = sign | 0x7f800000u | (man << 13);
+    } else {
+        u = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static bool loadExrRgba(const std::vector<uint8_t>& file, int& width, int& height, std::vector<float>& rgba, std::string& err)
+{
+    size_t pos = 0;
+    auto need = [&](size_t n) { return pos + n <= file.size(); };
+    auto rdI = [&](int32_t& v) { if (!need(4)) return false; memcpy(&v, &file[pos], 4); pos += 4; return true; };
+    auto rdStr = [&](std::string& t) {
+        t.clear();
+        while (pos < file.size() && file[pos]) t.push_back((char)file[pos++]);
+        if (pos >= file.size()) return false;
+        pos++;
+        return true;
+    };
+    int32_t magic = 0, version = 0;
+    if (!rdI(magic) || !rdI(version) || magic != 20000630) { err = "not an OpenEXR file"; return false; }
+    if ((version & 0xff) != 2 || (version & (0x200 | 0x800 | 0x1000))) { err = "tiled, deep or multi-part OpenEXR files are not supported"; return false; }
+    struct Channel { std::string name; int32_t type; };
+    std::vector<Channel> channels;
+    int32_t compression = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+    for (;;) {
+        std::string name, type;
+        if (!rdStr(name)) { err = "truncated header"; return false; }
+        if (name.empty()) break;
+        int32_t size = 0;
+        if (!rdStr(type) || !rdI(size) || size < 0 || !need((size_t)size)) { err = "truncated header"; return false; }
+        const size_t end = pos + (size_t)size;
+        if (name == "channels") {
+            for (;;) {
+                std::string cn;
+                if (!rdStr(cn) || pos > end) { err = "bad channel list"; return false; }
+                if (cn.empty()) break;
+                int32_t ct = 0, xs = 0, ys = 0;
+                if (!rdI(ct)) { err = "bad channel list"; return false; }
+                pos += 4; // pLinear + reserved
+                if (!rdI(xs) || !rdI(ys) || pos > end) { err = "bad channel list"; return false; }
+                if (xs != 1 || ys != 1) { err = "subsampled channels are not supported"; return false; }
+                if (ct < 0 || ct > 2) { err = "unknown channel type"; return false; }
+                channels.push_back({cn, ct});
+            }
+        } else if (name == "compression" && size >= 1) {
+            compression = file[pos];
+        } else if (name == "dataWindow" && size >= 16) {
+            memcpy(&x0, &file[pos], 4); memcpy(&y0, &file[pos + 4], 4); memcpy(&x1, &file[pos + 8], 4); memcpy(&y1, &file[pos + 12], 4);
+        }
+        pos = end;
+    }
+    if (channels.empty() || compression < 0 || x1 < x0 || y1 < y0) { err = "header lacks channels, compression or dataWindow"; return false; }
+    if (compression > 3) { err = "only NO / RLE / ZIPS / ZIP compression is read (this file uses PIZ, PXR24, B44 or DWA)"; return false; }
+    const int64_t w = (int64_t)x1 - x0 + 1, h = (int64_t)y1 - y0 + 1;
+    if (w > 65536 || h > 65536) { err = "image too large"; return false; }
+    width = (int)w;
+    height = (int)h;
+    // where each channel goes; the file stores the channels of a line one after the other, in the order of the list
+    size_t lineBytes = 0;
+    std::vector<size_t> chanOffset(channels.size());
+    std::vector<int> target(channels.size(), -1);
+    for (size_t c = 0; c < channels.size(); c++) {
+        chanOffset[c] = lineBytes;
+        lineBytes += (size_t)w * (channels[c].type == 1 ? 2u : 4u);
+        const std::string& n = channels[c].name;
+        if (n == "R") target[c] = 0;
+        else if (n == "G") target[c] = 1;
+        else if (n == "B") target[c] = 2;
+        else if (n == "A") target[c] = 3;
+    }
+    const bool grey = channels.size() == 1 && target[0] < 0;
+    rgba.assign((size_t)w * h * 4, 0.0f);
+    for (size_t i = 3; i < rgba.size(); i += 4) rgba[i] = 1.0f;
+    const uint32_t linesPerBlock = compression == 3 ? 16u : 1u, blocks = ((uint32_t)h + linesPerBlock - 1) / linesPerBlock;
+    if (!need((size_t)blocks * 8)) { err = "truncated offset table"; return false; }
+    const size_t table = pos;
+    std::vector<uint8_t> packed, raw, tmp;
+    for (uint32_t b = 0; b < blocks; b++) {
+        uint64_t off = 0;
+        memcpy(&off, &file[table + (size_t)b * 8], 8);
+        if (off + 8 > file.size()) { err = "bad block offset"; return false; }
+        int32_t y = 0, size = 0;
+        memcpy(&y, &file[off], 4);
+        memcpy(&size, &file[off + 4], 4);
+        if (size < 0 || off + 8 + (uint64_t)size > file.size() || y < y0 || y > y1) { err = "bad block"; return false; }
+        const uint32_t lines = std::min<uint32_t>(linesPerBlock, (uint32_t)(y1 - y + 1));
+        const size_t expect = lineBytes * lines;
+        const uint8_t* data = &file[off + 8];
+        if ((size_t)size == expect || compression == 0) { // stored as is (also what a writer does when packing does not help)
+            if ((size_t)size != expect) { err = "bad block size"; return false; }
+            raw.assign(data, data + size);
+        } else {
+            tmp.clear();
+            if (compression == 1) { // RLE: a count byte; negative = that many literal bytes, else count + 1 copies of the next byte
+                for (int32_t i = 0; i < size;) {
+                    const int8_t n = (int8_t)data[i++];
+                    if (n < 0) {
+                        const int32_t k = -(int32_t)n;
+                        if (i + k > size) { err = "bad RLE block"; return false; }
+                        tmp.insert(tmp.end(), data + i, data + i + k);
+                        i += k;
+                    } else {
+                        if (i >= size) { err = "bad RLE block"; return false; }
+                        tmp.insert(tmp.end(), (size_t)n + 1, data[i++]);
+                    }
+                }
+            } else {
+                packed.assign(data, data + size);
+                if (!inflateZlibBytes(packed, tmp)) { err = "bad ZIP block"; return false; }
+            }
+            if (tmp.size() != expect) { err = "block does not unpack to its size"; return false; }
+            for (size_t k = 1; k < tmp.size(); k++) tmp[k] = (uint8_t)(tmp[k - 1] + tmp[k] - 128); // predictor
+            raw.resize(expect);
+            const size_t half = (expect + 1) / 2; // first half: the even bytes, second half: the odd ones
+            for (size_t k = 0; k < expect; k++) raw[k] = tmp[(k & 1) ? half + k / 2 : k / 2];
+        }
+        for (uint32_t l = 0; l < lines; l++) {
+            float* row = &rgba[(size_t)(y - y0 + (int32_t)l) * w * 4];
+            for (size_t c = 0; c < channels.size(); c++) {
+                if (target[c] < 0 && !grey) continue;
+                const uint8_t* src = &raw[(size_t)l * lineBytes + chanOffset[c]];
+                for (int64_t x = 0; x < w; x++) {
+                    float v;
+                    if (channels[c].type == 1) {
+                        uint16_t hv;
+                        memcpy(&hv, src + 2 * x, 2);
+                        v = halfToFloat(hv);
+                    } else if (channels[c].type == 2) {
+                        memcpy(&v, src + 4 * x, 4);
+                    } else {
+                        uint32_t u;
+                        memcpy(&u, src + 4 * x, 4);
+                        v = (float)u;
+                    }
+                    if (grey) row[4 * x] = row[4 * x + 1] = row[4 * x + 2] = v;
+                    else row[4 * x + target[c]] = v;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// Besides OpenEXR this build reads a PFM ("PF", width height, scale;
 void InfiniteAreaLight::create(const char* path)
 {
     release();
@@ -189,6 +357,27 @@ void InfiniteAreaLight::create(const char* path)
         logPrintf(LogLevel::kError, "Failed to open '%s'\n", path);
         return;
     }
+    uint8_t head[4] = {0, 0, 0, 0};
+    const size_t headGot = fread(head, 1, 4, f);
+    if (headGot == 4 && head[0] == 0x76 && head[1] == 0x2f && head[2] == 0x31 && head[3] == 0x01) { // OpenEXR
+        fseek(f, 0, SEEK_END);
+        const long bytes = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> file(bytes > 0 ? (size_t)bytes : 0);
+        const size_t got = file.empty() ? 0 : fread(file.data(), 1, file.size(), f);
+        fclose(f);
+        int w = 0, h = 0;
+        std::vector<float> rgba;
+        std::string err;
+        if (got != file.size() || !loadExrRgba(file, w, h, rgba, err)) {
+            logPrintf(LogLevel::kError, "Load EXR err: %s(%s)\n", got != file.size() ? "short read" : err.c_str(), path); // texture.cpp:263
+            return;
+        }
+        logPrintf(LogLevel::kVerbose, "Loaded .exr '%s' (%d, %d)\n", path, w, h);
+        create(w, h, rgba.data());
+        return;
+    }
+    fseek(f, 0, SEEK_SET);
     char magic[3] = {0, 0, 0};
     int w = 0, h = 0;
     float scale = 0.0f;

@@ -1297,4 +1297,7 @@ Mesh SampleModels::getAtrium(uint32_t targetTris, uint32_t seed, bool alphaMaske
     return mesh;
 }
 
+// the same inflate for the OpenEXR reader's ZIP blocks (prt_host.cpp)
+bool inflateZlibBytes(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) { return inflateZlib(in, out); }
+
 } // namespace prt

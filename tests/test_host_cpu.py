@@ -203,6 +203,111 @@ def test_infinite_area_light_tables_match_oracle(L, tmp_path):
     assert scene3.arrays()["env"] is None
 
 
+def _write_exr(path, channels, x0, y0, compression):
+    """Test-side OpenEXR writer: `channels` = {name: (h, w) array of float16 / float32 / uint32}; scan lines, compression 0 (none),
+    1 (RLE), 2 (ZIPS) or 3 (ZIP); the data window starts at (x0, y0)."""
+    import struct
+    import zlib
+    names = sorted(channels)
+    h, w = channels[names[0]].shape
+    types = {np.dtype(np.uint32): 0, np.dtype(np.float16): 1, np.dtype(np.float32): 2}
+    hd = struct.pack("<ii", 20000630, 2)
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", types[channels[n].dtype], 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    hd += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([compression]))
+    hd += attr("dataWindow", "box2i", struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1))
+    hd += attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, x0 + w - 1, y0 + h - 1))
+    hd += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hd += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    per = 16 if compression == 3 else 1
+    blocks = []
+    for b0 in range(0, h, per):
+        raw = b"".join(channels[n][y].tobytes() for y in range(b0, min(h, b0 + per)) for n in names)
+        data = raw
+        if compression:
+            a = np.frombuffer(raw, dtype=np.uint8)
+            sh = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            sh[1:] = (sh[1:] - sh[:-1] + 128) & 255
+            pre = sh.astype(np.uint8).tobytes()
+            if compression == 1:  # RLE: runs of >= 3 equal bytes as (count - 1, byte), everything else as negative-count literals
+                out, i = bytearray(), 0
+                while i < len(pre):
+                    j = i
+                    while j + 1 < len(pre) and pre[j + 1] == pre[i] and j - i < 127:
+                        j += 1
+                    if j - i >= 2:
+                        out += bytes([j - i, pre[i]])
+                        i = j + 1
+                    else:
+                        k = i
+                        while k < len(pre) and k - i < 127 and not (k + 2 < len(pre) and pre[k] == pre[k + 1] == pre[k + 2]):
+                            k += 1
+                        out += bytes([(256 - (k - i)) & 255]) + pre[i:k]
+                        i = k
+                packed = bytes(out)
+            else:
+                packed = zlib.compress(pre, 6)
+            data = packed if len(packed) < len(raw) else raw
+        blocks.append(struct.pack("<ii", y0 + b0, len(data)) + data)
+    off = len(hd) + 8 * len(blocks)
+    table = b""
+    for blk in blocks:
+        table += struct.pack("<Q", off)
+        off += len(blk)
+    open(path, "wb").write(hd + table + b"".join(blocks))
+
+
+def test_environment_map_from_openexr(L, tmp_path):
+    """Scene::setInfiniteAreaLight(path) decodes an OpenEXR file in the reference (texture.cpp:256-310: tinyexr LoadEXR -> RGBA
+    float32, top row first).  tinyexr is absent; the reader here takes scan-line files with NO / RLE / ZIPS / ZIP blocks and UINT /
+    HALF / FLOAT channels: the product's own writer's files (HALF B, G, R: ZIP and raw), a test-side writer's files with float
+    channels incl. alpha, a data window off the origin, smooth rows (so that RLE runs and ZIP both bite) and a grey file; the CDF
+    tables built from the decoded texels equal those of the same texels passed in memory; PIZ is refused."""
+    rng = np.random.default_rng(11)
+    h, w = 37, 50  # three ZIP blocks, the last one short
+    rgb = (rng.random((h, w, 3), dtype=np.float32) * 6.0).astype(np.float32)
+    rgb[5:9] = 0.25  # constant rows
+    for zipped in (True, False):
+        p = tmp_path / f"own_{int(zipped)}.exr"
+        prt_amd.save_exr(str(p), rgb, zip=zipped)
+        scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+        scene.set_infinite_area_light(str(p))
+        got = scene.arrays()
+        want = np.concatenate([rgb.astype(np.float16).astype(np.float32), np.ones((h, w, 1), np.float32)], axis=2)
+        assert np.array_equal(got["env"].view(np.uint32), want.view(np.uint32)), f"own writer, zip={zipped}"
+        ref, _, _ = prt_amd.setup_cornell_box(32, 32)
+        ref.set_infinite_area_light(want)
+        assert np.array_equal(ref.arrays()["env_horizontal"].view(np.uint32), got["env_horizontal"].view(np.uint32))
+        assert np.array_equal(ref.arrays()["env_vertical"].view(np.uint32), got["env_vertical"].view(np.uint32))
+    smooth = np.linspace(0.0, 4.0, w, dtype=np.float32)[None, :].repeat(h, 0)
+    chans = {"R": rgb[..., 0].copy(), "G": smooth.copy(), "B": rgb[..., 2].astype(np.float16), "A": np.full((h, w), 0.5, np.float32),
+             "Z": rng.integers(0, 1000, (h, w)).astype(np.uint32)}  # Z: an extra channel the reader has to step over
+    for comp in (0, 1, 2, 3):
+        p = tmp_path / f"t{comp}.exr"
+        _write_exr(str(p), chans, 3, 5, comp)
+        scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+        scene.set_infinite_area_light(str(p))
+        got = scene.arrays()["env"]
+        want = np.stack([chans["R"], chans["G"], chans["B"].astype(np.float32), chans["A"]], axis=2)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"compression {comp}"
+    _write_exr(str(tmp_path / "grey.exr"), {"Y": rgb[..., 1].astype(np.float16)}, 0, 0, 3)
+    scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+    scene.set_infinite_area_light(str(tmp_path / "grey.exr"))
+    g = rgb[..., 1].astype(np.float16).astype(np.float32)
+    assert np.array_equal(scene.arrays()["env"], np.stack([g, g, g, np.ones_like(g)], axis=2))
+    _write_exr(str(tmp_path / "piz.exr"), {"R": rgb[..., 0]}, 0, 0, 0)
+    raw = bytearray(open(tmp_path / "piz.exr", "rb").read())
+    i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[i] = 4  # PIZ
+    open(tmp_path / "piz.exr", "wb").write(raw)
+    scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+    with pytest.raises(prt_amd.PrtError):
+        scene.set_infinite_area_light(str(tmp_path / "piz.exr"))
+    assert scene.arrays()["env"] is None
+
+
 def _tga(path, img, rle=False, top_down=False):
     """Write an 8-bit grey (h, w) or true-colour (h, w, 3|4) image as a TGA file."""
     import struct
