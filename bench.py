@@ -257,6 +257,18 @@ def main():
     kernel_ms = st["kernelMsSum"] / max(1, st["kernelLaunches"])
 
     out = None
+    gather_check = None
+    if rank == 0 and world > 1:
+        # untimed: the image the ranks' tiles were gathered into must equal what one GPU renders alone, bit for bit
+        gathered = fb.clone()
+        alone = torch.zeros_like(fb)
+        tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=alone.data_ptr(), stream=stream, exposure=exposure, rank=0, nranks=1)
+        torch.cuda.synchronize()
+        tracer.stats()
+        same = bool(torch.equal(gathered.view(torch.int32), alone.view(torch.int32)))
+        gather_check = f"the image gathered from {world} ranks equals the one-GPU image bit for bit" if same else \
+            f"MISMATCH: {int((gathered.view(torch.int32) != alone.view(torch.int32)).any(dim=2).sum().item())} pixels of the gathered image differ from the one-GPU image"
+        del gathered, alone
     if rank == 0:
         # algorithmic bytes of THIS rank's launch from an untimed counting launch (deterministic event counts)
         tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure, rank=rank, nranks=world,
@@ -278,7 +290,7 @@ def main():
             "config": {"workload": args.workload, "description": describe, "width": W, "height": H, "spp": spp, "max_depth": depth,
                        "seed": args.seed, "rays_per_step": int(rays_per_step), "occlusion_rays_per_step": int(occl_per_step),
                        "sharding": f"16x16 tiles round-robin over {world} rank(s), scene replicated, RCCL send/recv image gather of {tracer.gather_payload_bytes()} B per rank" if world > 1
-                       else "one GPU", "device": name, "compute_units": cus},
+                       else "one GPU", "device": name, "compute_units": cus, **({"gather_check": gather_check} if gather_check else {})},
             # `achieved` / `frac` are the contract's ALGORITHMIC figure (layout-independent bytes of the events the
             # reference's algorithm performs, most of them served by L1/L2) -- not a claim that DRAM is busy.  What DRAM and the
             # memory pipeline really do is beside it: `traffic` / `hbm_frac` (fabric-side counters) and `limiter` (from the same file).
