@@ -168,6 +168,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: whatever libraries print there while the run lasts (RCCL's version banner, for one) goes to
+    # stderr, and the line is written to the real stdout at the end
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import prt_amd
@@ -327,7 +332,7 @@ def main():
                 out["cpu_baseline"] = cb
             except Exception as e:  # the baseline is a report, never the product
                 out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
