@@ -487,7 +487,7 @@ static bool decodePng(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>&
 // separable IDCT (constants x 4096, +512 >> 10 after the columns, +65536 + (128 << 17) >> 17 after the rows), chroma
 // upsampling by the (3 near + 1 far + 2) >> 2 and (9, 3, 3, 1) / 16 triangle filters, and YCbCr -> RGB in 20-bit fixed point
 // (1.40200, 0.71414, 0.34414 with its & 0xffff0000, 1.77200).  No stb_image is at hand to pin this against (DESIGN.md
-// "parity status"); progressive and arithmetic-coded files are refused.
+// "parity status"); sequential and progressive Huffman-coded files; arithmetic-coded, lossless and hierarchical ones are refused.
 namespace {
 struct JpegHuff {
     uint8_t size[257];
@@ -522,6 +522,7 @@ struct JpegComp {
     int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, dcPred = 0;
     int x = 0, y = 0, w2 = 0, h2 = 0;
     std::vector<uint8_t> data;
+    std::vector<short> coeff; // progressive files: the coefficients of every block (w2 / 8 blocks per row), refined scan by scan
 };
 struct JpegDec {
     const uint8_t* p;
@@ -561,6 +562,25 @@ struct JpegDec {
         codeBits -= k;
         codeBuffer <<= k;
         return h.values[c];
+    }
+    int bit()
+    {
+        if (codeBits < 1) grow();
+        if (codeBits < 1) return 0;
+        const uint32_t k = codeBuffer;
+        codeBuffer <<= 1;
+        --codeBits;
+        return (int)(k >> 31);
+    }
+    int bits(int n)
+    {
+        if (n == 0) return 0;
+        if (codeBits < n) grow();
+        if (codeBits < n) return 0;
+        const uint32_t k = codeBuffer >> (32 - n);
+        codeBuffer <<= n;
+        codeBits -= n;
+        return (int)k;
     }
     int extend(int nbits) // receive + extend (ITU T.81 F.2.2.1)
     {
@@ -688,7 +708,7 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
     bool haveDc[4] = {false, false, false, false}, haveAc[4] = {false, false, false, false};
     JpegComp comp[3];
     int ncomp = 0, hmax = 1, vmax = 1, restart = 0;
-    bool sawFrame = false;
+    bool sawFrame = false, progressive = false;
     auto be16 = [&]() { int a = d.get8(); return (a << 8) | d.get8(); };
     for (;;) {
         int m = d.get8();
@@ -721,7 +741,8 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
         } else if (m == 0xdd) { // DRI
             if (be16() != 4) return false;
             restart = be16();
-        } else if (m == 0xc0 || m == 0xc1) { // SOF0 / SOF1
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) { // SOF0 / SOF1 (sequential), SOF2 (progressive)
+            progressive = (m == 0xc2);
             int L = be16();
             if (d.get8() != 8) return false;
             h = be16();
@@ -747,10 +768,11 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
                 comp[i].w2 = mcux * comp[i].h * 8;
                 comp[i].h2 = mcuy * comp[i].v * 8;
                 comp[i].data.assign((size_t)comp[i].w2 * comp[i].h2, 0);
+                if (progressive) comp[i].coeff.assign((size_t)comp[i].w2 * comp[i].h2, 0);
             }
             sawFrame = true;
-        } else if (m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-            return false; // progressive, lossless, arithmetic: not decoded here
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+            return false; // lossless, hierarchical, arithmetic: not decoded here
         } else if (m == 0xda) { // SOS: the one interleaved scan of a baseline file (or one scan per component)
             if (!sawFrame) return false;
             int L = be16(), ns = d.get8();
@@ -763,14 +785,112 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
                 if (which < 0) return false;
                 comp[which].hd = q >> 4;
                 comp[which].ha = q & 15;
-                if (comp[which].hd > 3 || comp[which].ha > 3 || !haveDc[comp[which].hd] || !haveAc[comp[which].ha]) return false;
+                if (comp[which].hd > 3 || comp[which].ha > 3) return false;
                 order[i] = which;
             }
-            d.get8(); d.get8(); d.get8(); // spectral selection and approximation: fixed for sequential files
+            const int specStart = d.get8(), specEnd = d.get8(), approx = d.get8(), succHigh = approx >> 4, succLow = approx & 15;
+            if (progressive) {
+                if (specStart > 63 || specEnd > 63 || specStart > specEnd || succHigh > 13 || succLow > 13) return false;
+                if (specStart != 0 && ns != 1) return false; // AC scans carry one component
+                for (int i = 0; i < ns; i++)
+                    if (specStart == 0 ? (succHigh == 0 && !haveDc[comp[order[i]].hd]) : !haveAc[comp[order[i]].ha]) return false;
+            } else {
+                for (int i = 0; i < ns; i++)
+                    if (!haveDc[comp[order[i]].hd] || !haveAc[comp[order[i]].ha]) return false;
+            }
             d.codeBuffer = 0; d.codeBits = 0; d.marker = 0xff; d.nomore = false;
             for (int i = 0; i < ncomp; i++) comp[i].dcPred = 0;
             int todo = restart ? restart : 0x7fffffff;
+            int eobRun = 0;
+            // one block of a progressive scan (ITU T.81 G.1.2, as stb_image decodes it: DC first / refinement, AC first / refinement)
+            auto blockProgressive = [&](JpegComp& c, short* data) -> bool {
+                if (specStart == 0) {
+                    if (specEnd != 0) return false; // a DC scan carries DC only
+                    if (succHigh == 0) {
+                        const int t = d.decode(hdc[c.hd]);
+                        if (t < 0 || t > 15) return false;
+                        const int diff = t ? d.extend(t) : 0;
+                        c.dcPred += diff;
+                        data[0] = (short)(c.dcPred * (1 << succLow));
+                    } else if (d.bit()) {
+                        data[0] = (short)(data[0] + (1 << succLow));
+                    }
+                    return true;
+                }
+                if (succHigh == 0) {
+                    if (eobRun) {
+                        --eobRun;
+                        return true;
+                    }
+                    int k = specStart;
+                    do {
+                        const int rs = d.decode(hac[c.ha]);
+                        if (rs < 0) return false;
+                        const int sz = rs & 15, r = rs >> 4;
+                        if (sz == 0) {
+                            if (r < 15) {
+                                eobRun = 1 << r;
+                                if (r) eobRun += d.bits(r);
+                                --eobRun;
+                                break;
+                            }
+                            k += 16;
+                        } else {
+                            k += r;
+                            const int zig = kJpegZigzag[k++];
+                            data[zig] = (short)(d.extend(sz) * (1 << succLow));
+                        }
+                    } while (k <= specEnd);
+                    return true;
+                }
+                const short bit = (short)(1 << succLow);
+                auto refine = [&](short* p) {
+                    if (d.bit() && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+                };
+                if (eobRun) {
+                    --eobRun;
+                    for (int k = specStart; k <= specEnd; ++k) {
+                        short* p = &data[kJpegZigzag[k]];
+                        if (*p != 0) refine(p);
+                    }
+                    return true;
+                }
+                int k = specStart;
+                do {
+                    const int rs = d.decode(hac[c.ha]);
+                    if (rs < 0) return false;
+                    int sz = rs & 15, r = rs >> 4;
+                    if (sz == 0) {
+                        if (r < 15) {
+                            eobRun = (1 << r) - 1;
+                            if (r) eobRun += d.bits(r);
+                            r = 64; // to the end of the band
+                        }
+                    } else {
+                        if (sz != 1) return false;
+                        sz = d.bit() ? bit : -bit;
+                    }
+                    while (k <= specEnd) {
+                        short* p = &data[kJpegZigzag[k++]];
+                        if (*p != 0) {
+                            refine(p);
+                        } else {
+                            if (r == 0) {
+                                *p = (short)sz;
+                                break;
+                            }
+                            --r;
+                        }
+                    }
+                } while (k <= specEnd);
+                return true;
+            };
             auto block = [&](JpegComp& c, uint8_t* out) -> bool {
+                if (progressive) { // `out` addresses the block's top-left sample: its coefficients live at the same block position
+                    const size_t off = (size_t)(out - c.data.data());
+                    const size_t by = off / ((size_t)c.w2 * 8), bx = (off % (size_t)c.w2) / 8;
+                    return blockProgressive(c, &c.coeff[(by * (size_t)(c.w2 / 8) + bx) * 64]);
+                }
                 short data[64];
                 memset(data, 0, sizeof(data));
                 if (d.codeBits < 16) d.grow();
@@ -804,6 +924,7 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
                 d.codeBuffer = 0; d.codeBits = 0; d.marker = 0xff; d.nomore = false;
                 for (int i = 0; i < ncomp; i++) comp[i].dcPred = 0;
                 todo = restart ? restart : 0x7fffffff;
+                eobRun = 0;
                 return true;
             };
             if (ns == 1) { // non-interleaved: the component's own blocks, row by row
@@ -848,6 +969,17 @@ static bool decodeJpeg(FILE* f, int& w, int& h, int& depth, std::vector<uint8_t>
         }
         if (d.pos >= d.n) return false;
     }
+    if (progressive) // every scan is in: dequantise and transform (stb_image: stbi__jpeg_finish)
+        for (int k = 0; k < ncomp; k++) {
+            JpegComp& c = comp[k];
+            const int bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    short* data = &c.coeff[((size_t)j * (c.w2 / 8) + i) * 64];
+                    for (int q = 0; q < 64; q++) data[q] = (short)(data[q] * dequant[c.tq][q]);
+                    jpegIdct(&c.data[(size_t)c.w2 * j * 8 + i * 8], c.w2, data);
+                }
+        }
     // ---- upsample and convert, one output row at a time
     depth = ncomp == 1 ? 1 : 3;
     raw.resize((size_t)w * h * depth);
@@ -976,7 +1108,7 @@ void parseMtl(const std::string& path, const std::string& dir, const std::vector
             bool bump = key != "map_Kd";
             Texture& t = bump ? cur->bumpMap : cur->diffuseMap;
             if (!loadTexture(dir + "/" + name, t, bump))
-                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM, PNG, sequential JPEG and TGA are read here: stb is not vendored)\n", name.c_str());
+                logPrintf(LogLevel::kError, "texture '%s' not loaded (binary PPM/PGM/PAM, PNG, Huffman-coded JPEG and TGA are read here: stb is not vendored)\n", name.c_str());
         }
     }
     for (auto& m : mats) m.alphaTest = m.diffuseMap.isAlphaTestRequired(); // material.cpp:79

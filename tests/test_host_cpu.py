@@ -543,6 +543,79 @@ def test_png_bit_depths_interlace_and_colour_keys(L, tmp_path, interlace):
     assert np.array_equal(load("k16.png"), want)
 
 
+def _load_texture_through_obj(tmp_path, name):
+    (tmp_path / "q.mtl").write_text(f"newmtl a\nKd 1 1 1\nmap_Kd {name}\n")
+    (tmp_path / "q.obj").write_text("mtllib q.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n")
+    sc = prt_amd.Scene()
+    sc.add(prt_amd.Mesh.load_obj(str(tmp_path / "q.obj")))
+    return sc.arrays()["textures"][0]
+
+
+def test_png_and_jpeg_files_written_by_an_independent_library(L, tmp_path):
+    """The texture decoders against files they did not write themselves: Pillow (libpng / libjpeg) encodes, where it is
+    installed, and the decoders must give libpng's pixels exactly and libjpeg's within the arithmetic difference between two
+    conforming JPEG decoders (stb_image's integer IDCT and fixed-point YCbCr, which the decoder restates, against libjpeg's).
+    Covers what the test-side writers cannot vouch for: real Huffman and quantisation tables, optimised tables, restart
+    intervals, 4:4:4 / 4:2:2 / 4:2:0 sampling, progressive files, palette files with transparency, zlib streams of several block types."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    h, w = 61, 83  # ragged against 8 and 16
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 3) % 256, (yy * 4) % 256, ((xx + yy) * 2) % 256], axis=2).astype(np.uint8)
+    noisy = np.clip(smooth.astype(np.int32) + rng.integers(-20, 21, smooth.shape), 0, 255).astype(np.uint8)
+
+    def expect(im):  # Texture::load (texture.cpp:218-249): one channel for grey files, RGBA otherwise
+        a = np.asarray(im)
+        if a.ndim == 2: return a[..., None]
+        if a.shape[2] == 2: return np.dstack([a[..., 0]] * 3 + [a[..., 1]])
+        if a.shape[2] == 3: return np.dstack([a, np.full(a.shape[:2], 255, np.uint8)])
+        return a
+
+    # ---- PNG: exact
+    for mode, arr in (("RGB", noisy), ("RGBA", np.dstack([noisy, smooth[..., 0]])), ("L", noisy[..., 0]), ("LA", np.dstack([noisy[..., 0], smooth[..., 1]]))):
+        for level in (0, 1, 9):
+            Image.fromarray(arr, mode).save(tmp_path / "a.png", compress_level=level)
+            assert np.array_equal(_load_texture_through_obj(tmp_path, "a.png"), expect(Image.open(tmp_path / "a.png"))), (mode, level)
+    pal = Image.fromarray(noisy, "RGB").quantize(37)
+    pal.save(tmp_path / "p.png", transparency=5)
+    got = _load_texture_through_obj(tmp_path, "p.png")
+    assert np.array_equal(got, np.asarray(Image.open(tmp_path / "p.png").convert("RGBA"))), "palette with transparency"
+    # ---- JPEG: within the difference between two conforming decoders
+    for name, kw, tol in (("444 q95", dict(quality=95, subsampling=0), 3), ("422 q90", dict(quality=90, subsampling=1), 6),
+                          ("420 q85 optimised", dict(quality=85, subsampling=2, optimize=True), 8), ("420 q60", dict(quality=60, subsampling=2), 8)):
+        Image.fromarray(smooth, "RGB").save(tmp_path / "a.jpg", **kw)
+        got = _load_texture_through_obj(tmp_path, "a.jpg").astype(np.int32)
+        want = expect(Image.open(tmp_path / "a.jpg").convert("RGB")).astype(np.int32)
+        assert got.shape == want.shape, name
+        d = np.abs(got - want)
+        if kw["subsampling"] == 1:
+            # stb_image's horizontal 2x resampler weighs the last pair of a row the other way round than libjpeg
+            # ((3 * in[w-2] + in[w-1]) / 4 where libjpeg has 3 * in[w-1] + in[w-2]); the decoder follows stb_image, so the last
+            # two columns are compared loosely
+            assert d[:, -2:].max() <= 128
+            d = d[:, :-2]
+        assert d.max() <= tol and d.mean() < 0.8, (name, int(d.max()), float(d.mean()))
+    Image.fromarray(noisy[..., 0], "L").save(tmp_path / "g.jpg", quality=92)
+    got = _load_texture_through_obj(tmp_path, "g.jpg").astype(np.int32)
+    want = expect(Image.open(tmp_path / "g.jpg")).astype(np.int32)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2, "grey"
+    # progressive files (SOF2: spectral selection and successive approximation, DC and AC refinement scans, end-of-band runs)
+    for name, arr, mode, kw, tol in (("progressive 444", smooth, "RGB", dict(quality=92, subsampling=0), 3), ("progressive 420", smooth, "RGB", dict(quality=80, subsampling=2), 8),
+                                     ("progressive 420 noisy", noisy, "RGB", dict(quality=50, subsampling=2), 10), ("progressive grey", noisy[..., 1], "L", dict(quality=88), 2)):
+        Image.fromarray(arr, mode).save(tmp_path / "pr.jpg", progressive=True, **kw)
+        assert b"\xff\xc2" in open(tmp_path / "pr.jpg", "rb").read(), "the file is not progressive"
+        got = _load_texture_through_obj(tmp_path, "pr.jpg").astype(np.int32)
+        want = expect(Image.open(tmp_path / "pr.jpg").convert(mode)).astype(np.int32)
+        assert got.shape == want.shape, name
+        d = np.abs(got - want)
+        assert d.max() <= tol and d.mean() < 0.9, (name, int(d.max()), float(d.mean()))
+    raw = bytearray(open(tmp_path / "pr.jpg", "rb").read())
+    raw[raw.index(b"\xff\xc2") + 1] = 0xc9  # arithmetic coding: refused with a message (the material keeps no map), not misread
+    open(tmp_path / "ar.jpg", "wb").write(raw)
+    with pytest.raises(IndexError):
+        _load_texture_through_obj(tmp_path, "ar.jpg")
+
+
 _ZZ = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50,
        43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
 
