@@ -580,6 +580,16 @@ def test_png_and_jpeg_files_written_by_an_independent_library(L, tmp_path):
     pal.save(tmp_path / "p.png", transparency=5)
     got = _load_texture_through_obj(tmp_path, "p.png")
     assert np.array_equal(got, np.asarray(Image.open(tmp_path / "p.png").convert("RGBA"))), "palette with transparency"
+    # interlaced and 16-bit files from the test-side writer: Pillow must read them as the decoder does (the writer is sound too)
+    v8 = rng.integers(0, 256, size=(h, w, 4))
+    _png_general(tmp_path / "i.png", v8, 8, 6, True)
+    assert np.array_equal(_load_texture_through_obj(tmp_path, "i.png"), np.asarray(Image.open(tmp_path / "i.png").convert("RGBA"))), "Adam7"
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "i.png")), v8.astype(np.uint8))
+    # ---- TGA: exact (24 / 32 bit, raw and run-length encoded)
+    for mode, arr in (("RGB", noisy), ("RGBA", np.dstack([smooth, noisy[..., 2]])), ("L", smooth[..., 0])):
+        for comp in (None, "tga_rle"):
+            Image.fromarray(arr, mode).save(tmp_path / "a.tga", **({"compression": comp} if comp else {}))
+            assert np.array_equal(_load_texture_through_obj(tmp_path, "a.tga"), expect(Image.open(tmp_path / "a.tga"))), (mode, comp)
     # ---- JPEG: within the difference between two conforming decoders
     for name, kw, tol in (("444 q95", dict(quality=95, subsampling=0), 3), ("422 q90", dict(quality=90, subsampling=1), 6),
                           ("420 q85 optimised", dict(quality=85, subsampling=2, optimize=True), 8), ("420 q60", dict(quality=60, subsampling=2), 8)):
