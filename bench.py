@@ -173,6 +173,7 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     sys.stdout.flush()
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (before anything initialises HIP: RCCL needs dmabuf IPC on this pool)
     import torch
     import torch.distributed as dist
     import prt_amd
