@@ -44,8 +44,43 @@ PRT_HD double prt_mad(double a, double b, double c)
 #endif
 }
 
-// One shared reduction: theta in [pi/4, 120) -> (x in [-pi/4,pi/4], quadrant n).
-// theta below pi/4 uses n = 0 with no reduction.
+// 4/pi in 24 overlapping 32-bit windows, 8 bits apart (glibc sincosf_data.c: __inv_pio4), for arguments of 120 and beyond
+PRT_HD uint32_t prt_inv_pio4(uint32_t i)
+{
+    // the bit string a2f9836e 4e441529 fc2757d1 f534ddc0 db629599 3c439041, window i = its bits [8 i - 24, 8 i + 8)
+    const uint32_t w[6] = {0xa2f9836eu, 0x4e441529u, 0xfc2757d1u, 0xf534ddc0u, 0xdb629599u, 0x3c439041u};
+    const int first = 8 * (int)i - 24; // may be negative: leading zeros
+    uint64_t acc = 0;
+    for (int b = 0; b < 32; b++) {
+        const int bit = first + b;
+        uint32_t v = 0;
+        if (bit >= 0) v = (w[bit >> 5] >> (31 - (bit & 31))) & 1u;
+        acc = (acc << 1) | v;
+    }
+    return (uint32_t)acc;
+}
+
+// Reduction of |y| >= 120 by exact integer arithmetic on the bits of 4/pi (glibc sincosf.h: reduce_large): returns x in
+// [-pi/4, pi/4] and the quadrant.
+PRT_HD double prt_reduce_large(uint32_t xi, int* np)
+{
+    const uint32_t base = (xi >> 26) & 15u;
+    const int shift = (int)((xi >> 23) & 7u);
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * prt_inv_pio4(base)); // the low 32 bits of the product, as the 32-bit multiply gives them
+    const uint64_t res1 = (uint64_t)xi * prt_inv_pio4(base + 4);
+    const uint64_t res2 = (uint64_t)xi * prt_inv_pio4(base + 8);
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+}
+
+// One shared reduction: |theta| in [pi/4, 120) -> (x in [-pi/4,pi/4], quadrant n) in one double-precision step; from 120 on
+// the integer reduction above; below pi/4 n = 0 with no reduction; infinities and NaNs give NaN.
 PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
 {
     const double hpi_inv = 0x1.45F306DC9C883p+23; // 2/pi * 2^24
@@ -55,7 +90,7 @@ PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
     const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
 
     double x = (double)y;
-    int n = 0;
+    int n = 0, q = 0;
     uint32_t top = (prt_f2u(y) >> 20) & 0x7ff;
     const uint32_t top_pio4 = (0x3f490fdbu >> 20) & 0x7ff;
     const uint32_t top_tiny = (0x39800000u >> 20) & 0x7ff; // 0x1p-12f
@@ -65,14 +100,21 @@ PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
             *cosp = 1.0f;
             return;
         }
-    } else {
+    } else if (top < ((0x42f00000u >> 20) & 0x7ff)) { // |y| < 120
         double r = x * hpi_inv;
         n = ((int32_t)r + 0x800000) >> 24;
         x = prt_mad(-(double)n, hpi, x);
+    } else if (top < ((0x7f800000u >> 20) & 0x7ff)) {
+        x = prt_reduce_large(prt_f2u(y), &n);
+        q = n + (int)(prt_f2u(y) >> 31); // the sign of y moves the sign and the table choice, not the sine / cosine choice
+    } else {
+        *sinp = *cosp = y - y; // NaN (and the invalid exception in libm)
+        return;
     }
-    // sign table {1,-1,-1,1}[n&3] for the sine argument; polynomial negated when n&2
-    double sgn = ((n + 1) & 2) ? -1.0 : 1.0;
-    double neg = (n & 2) ? -1.0 : 1.0;
+    if (top < ((0x42f00000u >> 20) & 0x7ff)) q = n;
+    // sign table {1,-1,-1,1}[q&3] for the sine argument; polynomial negated when q&2
+    double sgn = ((q + 1) & 2) ? -1.0 : 1.0;
+    double neg = (q & 2) ? -1.0 : 1.0;
     double x2 = x * x;
     double xs = x * sgn;
     // sine polynomial on xs (sine coefficients are not negated in the second table)

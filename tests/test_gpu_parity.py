@@ -88,6 +88,21 @@ def test_sincos_matches_libm_on_all_path_arguments(rows, oracle_lib):
     oracle_lib.orc_libm_sincos(len(theta), T.vptr(theta), T.vptr(rs), T.vptr(rc))
     assert_bits_equal(s, rs, "sinf")
     assert_bits_equal(c, rc, "cosf")
+    # Environment light (light.cpp:121-125): theta = 2 pi (u + 0.5) and phi = pi v with (u, v) from the inverted CDFs -- a bright
+    # texel in the first row or column makes them any size and sign (profiles/r02_parity_sweeps.txt: found by the sweep), so the
+    # whole float line matters: every 997th bit pattern, all of [-300, 300] around the switch of reductions at 120, infinities, NaN.
+    bits = np.concatenate([np.arange(0, 1 << 32, 997, dtype=np.uint64).astype(np.uint32),
+                           np.arange(np.float32(100).view(np.uint32), np.float32(300).view(np.uint32), dtype=np.uint32),
+                           np.arange(np.float32(100).view(np.uint32), np.float32(300).view(np.uint32), dtype=np.uint32) | np.uint32(0x80000000),
+                           np.array([0x7F800000, 0xFF800000, 0x7FC00000, 0x7F7FFFFF, 0xFF7FFFFF], dtype=np.uint32)])
+    y = bits.view(np.float32)
+    s, c = rows.test_sincos(y)
+    rs, rc = np.zeros_like(y), np.zeros_like(y)
+    oracle_lib.orc_libm_sincos(len(y), T.vptr(y), T.vptr(rs), T.vptr(rc))
+    nan = np.isnan(rs)
+    assert np.array_equal(np.isnan(s), nan) and np.array_equal(np.isnan(c), np.isnan(rc))
+    assert_bits_equal(s[~nan], rs[~nan], "sinf over the float line")
+    assert_bits_equal(c[~nan], rc[~nan], "cosf over the float line")
 
 
 def test_powf_matches_libm(rows, oracle_lib):
@@ -435,6 +450,21 @@ def test_infinite_area_light_matches_reference_and_oracle(tracer):
     ref, ost = s.render(16, max_depth=8)
     assert ost["occludedTraced"] > 0
     assert_bits_equal(rgb, ref, "env-lit Cornell + teapot vs oracle")
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    # A very bright texel in the first row and column: entry 0 of both CDFs then exceeds most draws, the scan settles on the first
+    # entry that differs from its predecessor and the offsets (u - prev) / pdf are large and negative -- the angles theta and phi
+    # leave every small range (sinf / cosf by the reduction for |x| >= 120).  Found by tools/misc_sweep.py.
+    env = T.sky_env(24, 12)
+    env[0, 0, :3] = 5000.0
+    scene, camera, exposure = prt_amd.setup_cornell_box(96, 64)
+    scene.set_infinite_area_light(env)
+    upload(tracer, scene, camera)
+    desc = T.scene_desc_from_product(scene, camera, exposure)
+    rgb = tracer.render(16, max_depth=6, count_traffic=True)
+    st = tracer.last_stats
+    ref, ost = T.OracleScene(desc).render(16, max_depth=6)
+    assert_bits_equal(rgb, ref, "environment map with a bright first texel")
     for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
         assert st[k] == ost[k], (k, st[k], ost[k])
     # a directional light set afterwards switches the environment light off (scene.h:30-35)

@@ -147,7 +147,8 @@ def test_bvh_build_matches_oracle_on_random_soups(L, n, seed):
 
 
 def test_devmath_matches_libm_on_every_path_argument(tmp_path):
-    """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce and every float in [-0.5, 10] (environment light angles);
+    """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce, every float in [-0.5, 10] and a 1/61 sample of the whole float line
+    (environment light angles: both reductions of glibc's sinf / cosf, below and from 120, infinities, NaN);
     powf(x, 2.2): every float in [2^-24, 1]."""
     src = tmp_path / "dm.c"
     src.write_text(r'''
@@ -163,6 +164,11 @@ int main(){ const float kPi = 3.14159265358979323846f; long bad=0;
   for(int neg=0;neg<2;neg++){ float top=neg?0.5f:10.0f; uint32_t hi; memcpy(&hi,&top,4);
     for(uint32_t b=0;b<=hi;b++){ uint32_t bb=b|(neg?0x80000000u:0u); float y; memcpy(&y,&bb,4);
       float s,c; prt_sincosf(y,&s,&c); float gs=sinf(y), gc=cosf(y); if(memcmp(&s,&gs,4)||memcmp(&c,&gc,4)) bad++; } }
+  /* ... and a bright texel in the first row or column of the environment map makes (u, v) any size and sign: every 61st bit pattern of the
+     whole float line (all 2^32 were checked once: 0 mismatches), infinities and NaNs included */
+  for(uint64_t b=0;b<(1ull<<32);b+=61){ uint32_t bb=(uint32_t)b; float y; memcpy(&y,&bb,4);
+    float s,c; prt_sincosf(y,&s,&c); float gs=sinf(y), gc=cosf(y);
+    if(!((isnan(gs)? isnan(s) : !memcmp(&s,&gs,4)) && (isnan(gc)? isnan(c) : !memcmp(&c,&gc,4)))) bad++; }
   for(uint32_t b=0x33800000u;b<=0x3f800000u;b++){ float x; memcpy(&x,&b,4); float m=prt_powf_2p2(x), g=powf(x,2.2f); if(memcmp(&m,&g,4)) bad++; }
   float z=0.0f, m=prt_powf_2p2(z), g=powf(z,2.2f); if(memcmp(&m,&g,4)) bad++;
   printf("%%ld\n", bad); return 0; }
