@@ -44,20 +44,15 @@ PRT_HD double prt_mad(double a, double b, double c)
 #endif
 }
 
-// 4/pi in 24 overlapping 32-bit windows, 8 bits apart (glibc sincosf_data.c: __inv_pio4), for arguments of 120 and beyond
+// 4/pi in 24 overlapping 32-bit windows, 8 bits apart (glibc sincosf_data.c: __inv_pio4: window i holds bits [8 i - 24, 8 i + 8)
+// of a2f9836e 4e441529 fc2757d1 f534ddc0 db629599 3c439041), for arguments of 120 and beyond.  A table in constant memory:
+// computed in registers, or reached through a call, the rare path cost the shade pass 2-12 % of a frame in spills.
 PRT_HD uint32_t prt_inv_pio4(uint32_t i)
 {
-    // the bit string a2f9836e 4e441529 fc2757d1 f534ddc0 db629599 3c439041, window i = its bits [8 i - 24, 8 i + 8)
-    const uint32_t w[6] = {0xa2f9836eu, 0x4e441529u, 0xfc2757d1u, 0xf534ddc0u, 0xdb629599u, 0x3c439041u};
-    const int first = 8 * (int)i - 24; // may be negative: leading zeros
-    uint64_t acc = 0;
-    for (int b = 0; b < 32; b++) {
-        const int bit = first + b;
-        uint32_t v = 0;
-        if (bit >= 0) v = (w[bit >> 5] >> (31 - (bit & 31))) & 1u;
-        acc = (acc << 1) | v;
-    }
-    return (uint32_t)acc;
+    static const uint32_t tab[24] = {0xa2u,       0xa2f9u,     0xa2f983u,   0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+                                     0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
+                                     0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+    return tab[i];
 }
 
 // Reduction of |y| >= 120 by exact integer arithmetic on the bits of 4/pi (glibc sincosf.h: reduce_large): returns x in
@@ -79,39 +74,13 @@ PRT_HD double prt_reduce_large(uint32_t xi, int* np)
     return (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
 }
 
-// One shared reduction: |theta| in [pi/4, 120) -> (x in [-pi/4,pi/4], quadrant n) in one double-precision step; from 120 on
-// the integer reduction above; below pi/4 n = 0 with no reduction; infinities and NaNs give NaN.
-PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
+// The two polynomials on the reduced argument x in [-pi/4, pi/4] (glibc sincosf.h: sincosf_poly): n picks which of them is the
+// sine, q the sign of the sine's argument and whether the cosine's coefficients are negated.
+PRT_HD void prt_sincosf_poly(double x, int n, int q, float* sinp, float* cosp)
 {
-    const double hpi_inv = 0x1.45F306DC9C883p+23; // 2/pi * 2^24
-    const double hpi = 0x1.921FB54442D18p0;       // pi/2
     const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
                  c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
     const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
-
-    double x = (double)y;
-    int n = 0, q = 0;
-    uint32_t top = (prt_f2u(y) >> 20) & 0x7ff;
-    const uint32_t top_pio4 = (0x3f490fdbu >> 20) & 0x7ff;
-    const uint32_t top_tiny = (0x39800000u >> 20) & 0x7ff; // 0x1p-12f
-    if (top < top_pio4) {
-        if (top < top_tiny) { // |y| < 2^-12: sin = y, cos = 1
-            *sinp = y;
-            *cosp = 1.0f;
-            return;
-        }
-    } else if (top < ((0x42f00000u >> 20) & 0x7ff)) { // |y| < 120
-        double r = x * hpi_inv;
-        n = ((int32_t)r + 0x800000) >> 24;
-        x = prt_mad(-(double)n, hpi, x);
-    } else if (top < ((0x7f800000u >> 20) & 0x7ff)) {
-        x = prt_reduce_large(prt_f2u(y), &n);
-        q = n + (int)(prt_f2u(y) >> 31); // the sign of y moves the sign and the table choice, not the sine / cosine choice
-    } else {
-        *sinp = *cosp = y - y; // NaN (and the invalid exception in libm)
-        return;
-    }
-    if (top < ((0x42f00000u >> 20) & 0x7ff)) q = n;
     // sign table {1,-1,-1,1}[q&3] for the sine argument; polynomial negated when q&2
     double sgn = ((q + 1) & 2) ? -1.0 : 1.0;
     double neg = (q & 2) ? -1.0 : 1.0;
@@ -123,7 +92,7 @@ PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
     double x7 = x3 * x2;
     double sv = prt_mad(x3, s1, xs);
     double sres = prt_mad(x7, sp1, sv);
-    // cosine polynomial (coefficients negated when n & 2)
+    // cosine polynomial (coefficients negated when q & 2)
     double x4 = x2 * x2;
     double cp2 = prt_mad(x2, neg * c4, neg * c3);
     double cp1 = prt_mad(x2, neg * c1, neg * c0);
@@ -137,6 +106,48 @@ PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
         *sinp = (float)sres;
         *cosp = (float)cres;
     }
+}
+
+// |y| >= 120, infinities and NaNs (glibc: reduce_large; the sign of y moves the sign and the table choice, not the sine /
+// cosine choice).  The path's own angles never come here, an environment map's can (light.cpp:121-125).
+PRT_HD void prt_sincosf_large(float y, float* sinp, float* cosp)
+{
+    const uint32_t bits = prt_f2u(y);
+    if ((bits & 0x7f800000u) == 0x7f800000u) {
+        *sinp = *cosp = y - y; // NaN (and the invalid exception in libm)
+        return;
+    }
+    int n;
+    const double x = prt_reduce_large(bits, &n);
+    prt_sincosf_poly(x, n, n + (int)(bits >> 31), sinp, cosp);
+}
+
+// One shared reduction: |theta| in [pi/4, 120) -> (x in [-pi/4,pi/4], quadrant n) in one double-precision step; below pi/4
+// n = 0 with no reduction.
+PRT_HD void prt_sincosf(float y, float* sinp, float* cosp)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23; // 2/pi * 2^24
+    const double hpi = 0x1.921FB54442D18p0;       // pi/2
+    double x = (double)y;
+    int n = 0;
+    uint32_t top = (prt_f2u(y) >> 20) & 0x7ff;
+    const uint32_t top_pio4 = (0x3f490fdbu >> 20) & 0x7ff;
+    const uint32_t top_tiny = (0x39800000u >> 20) & 0x7ff; // 0x1p-12f
+    if (top < top_pio4) {
+        if (top < top_tiny) { // |y| < 2^-12: sin = y, cos = 1
+            *sinp = y;
+            *cosp = 1.0f;
+            return;
+        }
+    } else if (top < ((0x42f00000u >> 20) & 0x7ff)) { // |y| < 120
+        double r = x * hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = prt_mad(-(double)n, hpi, x);
+    } else {
+        prt_sincosf_large(y, sinp, cosp);
+        return;
+    }
+    prt_sincosf_poly(x, n, n, sinp, cosp);
 }
 
 // powf(x, 2.2f) for x >= 0 as glibc 2.35 computes it (sysdeps/ieee754/flt-32/e_powf.c: log2 by a
