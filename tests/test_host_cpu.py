@@ -149,7 +149,7 @@ def test_bvh_build_matches_oracle_on_random_soups(L, n, seed):
 def test_devmath_matches_libm_on_every_path_argument(tmp_path):
     """sincos: all 2^23 theta = 2*pi*r1 the bounce can produce, every float in [-0.5, 10] and a 1/61 sample of the whole float line
     (environment light angles: both reductions of glibc's sinf / cosf, below and from 120, infinities, NaN);
-    powf(x, 2.2): every float in [2^-24, 1]."""
+    powf(x, 2.2): every float in [2^-24, 2] and a 1/13 sample below (a bilinear texel mix can leave [0, 1] by a rounding)."""
     src = tmp_path / "dm.c"
     src.write_text(r'''
 #include <stdio.h>
@@ -171,6 +171,10 @@ int main(){ const float kPi = 3.14159265358979323846f; long bad=0;
     if(!((isnan(gs)? isnan(s) : !memcmp(&s,&gs,4)) && (isnan(gc)? isnan(c) : !memcmp(&c,&gc,4)))) bad++; }
   for(uint32_t b=0x33800000u;b<=0x3f800000u;b++){ float x; memcpy(&x,&b,4); float m=prt_powf_2p2(x), g=powf(x,2.2f); if(memcmp(&m,&g,4)) bad++; }
   float z=0.0f, m=prt_powf_2p2(z), g=powf(z,2.2f); if(memcmp(&m,&g,4)) bad++;
+  /* a bilinear mix can leave [2^-24, 1] by a rounding (weights that sum to 1 + ulp; a weight of 1e-8): every float in [1, 2] and every 13th
+     below 2^-24, denormals included (all of [0, 2] were checked once: 0 mismatches) */
+  for(uint32_t b=0x3f800000u;b<=0x40000000u;b++){ float x; memcpy(&x,&b,4); float mm=prt_powf_2p2(x), gg=powf(x,2.2f); if(memcmp(&mm,&gg,4)) bad++; }
+  for(uint32_t b=0;b<0x33800000u;b+=13){ float x; memcpy(&x,&b,4); float mm=prt_powf_2p2(x), gg=powf(x,2.2f); if(memcmp(&mm,&gg,4)) bad++; }
   printf("%%ld\n", bad); return 0; }
 ''' % T.ROOT)
     exe = tmp_path / "dm"
