@@ -107,7 +107,8 @@ def test_sincos_matches_libm_on_all_path_arguments(rows, oracle_lib):
 
 def test_powf_matches_libm(rows, oracle_lib):
     rng = np.random.default_rng(5)
-    x = np.concatenate([rng.uniform(0, 1, 1 << 20), np.arange(256) / 255.0, [0.0, 1.0, 1e-30, 2.0 ** -24]]).astype(np.float32)
+    x = np.concatenate([rng.uniform(0, 1, 1 << 20), np.arange(256) / 255.0, [0.0, 1.0, 1e-30, 2.0 ** -24], rng.uniform(1, 2, 1 << 16),
+                        np.exp(rng.uniform(np.log(1e-44), np.log(1e-7), 1 << 16))]).astype(np.float32)  # a texel mix can round just outside [0, 1]
     y = rows.test_powf(x)
     ref = np.zeros_like(x)
     oracle_lib.orc_libm_powf22(len(x), T.vptr(x), T.vptr(ref))
