@@ -309,7 +309,7 @@ def main():
                                      f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f} of the frame, "
                                      f"L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit {ev['derived']['l2_hit_rate']:.2f}, "
                                      f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction; "
-                                     "+22 % vector instructions cost +4 % time (DESIGN.md 4.3)") if ev
+                                     "+22 % vector instructions cost +4 % time; the vector ALU is 72 % busy -- the second roof, 1.39x away (DESIGN.md 4.3)") if ev
                          else "see profiles/ (no counter summary taken with these kernel sources)",
                          "kernel": "frame_kernel: one persistent launch per frame (shade passes + four ray traversals as roles of its waves)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(B),
