@@ -108,49 +108,67 @@ def host_cores():
     return int(env) if env else n
 
 
-def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, want_seconds=15.0):
-    """The CPU path timed on this box's host cores (all of them) on a bounded sample of the same workload: a centred
-    window of the image, sized from a quick probe so that the timed run takes about want_seconds.
+def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, budget_seconds, gpu_render_cap14):
+    """The CPU path timed on this box's host cores (all of them).
 
-    kind "reference": the reference's own compiled code (oracle/_ref/ref_path, AVX2 8-wide, built from the reference's
-    sources by oracle/Makefile).  Its depth cap is the literal 14 (path_tracer.cpp:124), so when the workload's cap
-    differs the window is traced at 14 -- Mray/s is a rate, and the oracle port's rate at the workload's own cap is
-    reported beside it ("port_value").  kind "port": oracle/prt_oracle.c (scalar C, OpenMP over tiles) when the
-    reference binary is not there."""
+    kind "reference+glue": the reference's own compiled code (oracle/_ref/ref_path: the reference's path_tracer / bvh / scene /
+    camera / triangle / light objects, AVX2 8-wide, built from its sources by oracle/Makefile, linked with oracle/ref_glue.cpp
+    for the four translation units that cannot be built here -- surface fetch and texture taps are the oracle's scalar C)
+    on the WHOLE frame of the workload, what the reference's main.cpp:120-183 times.  Its depth cap is the literal 14
+    (path_tracer.cpp:124), so the GPU renders the same whole frame once more at cap 14 (`gpu_render_cap14`): ONE ratio, identical
+    pixels, identical cap -- and the two images are compared bit for bit while they are there.  Rays are the GPU launch's count
+    (deterministic; the parity suite requires it equal to the oracle's and the compiled reference's).  Only when a probe says
+    the whole frame would not fit `budget_seconds` is a centred window traced instead (both sides on the window).
+    kind "port": oracle/prt_oracle.c (scalar C, OpenMP over tiles) on a window, when the reference binary is not there."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import prt_testlib as T
     desc = T.scene_desc_from_product(scene, camera, exposure)
     W, H = camera.width, camera.height
     cores = host_cores()
-    s = T.OracleScene(desc)
 
     def window(frac):
         w, h = max(16, int(W * frac) // 16 * 16), max(16, int(H * frac) // 16 * 16)
         x0, y0 = (W - w) // 2 // 16 * 16, (H - h) // 2 // 16 * 16
         return x0, y0, min(W - 1, x0 + w - 1), min(H - 1, y0 + h - 1)
 
-    def run_port(rect, depth, stats):
-        t0 = time.time()
-        _, st = s.render_rect(rect, spp, max_depth=depth, seed=seed, threads=cores, stats=stats)
-        return time.time() - t0, st["raysTraced"]
+    if T.ref_binary("ref_path") is None:
+        s = T.OracleScene(desc)
 
-    probe = window(0.06)
-    sec, _ = run_port(probe, max_depth, False)
-    frac = min(1.0, 0.06 * (want_seconds / max(sec, 1e-3)) ** 0.5)
-    rect = window(frac)
-    _, rays = run_port(rect, max_depth, True)          # counting pass (not timed)
-    port_sec, _ = run_port(rect, max_depth, False)     # timed pass without counters
-    out = dict(value=rays / port_sec / 1e6, unit="Mray/s", cores=cores, kind="port",
-               sample=f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image at {spp} spp, depth cap {max_depth}: "
-                      f"{rays} rays in {port_sec:.2f} s on {cores} threads (oracle port)")
-    if T.ref_binary("ref_path") is not None:
-        _, rays14 = run_port(rect, 14, True) if max_depth != 14 else (0, rays)
-        _, rst = T.ref_render(desc, spp, rect, seed=seed, threads=cores, stats=False)
-        out = dict(value=rays14 / rst["seconds"] / 1e6, unit="Mray/s", cores=cores, kind="reference", port_value=out["value"],
-                   sample=f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image at {spp} spp: compiled reference "
-                          f"(depth cap 14, its literal) {rays14} rays in {rst['seconds']:.2f} s on {cores} threads; "
-                          f"oracle port at depth cap {max_depth}: {rays} rays in {port_sec:.2f} s")
-    return out
+        def run_port(rect, stats):
+            t0 = time.time()
+            _, st = s.render_rect(rect, spp, max_depth=max_depth, seed=seed, threads=cores, stats=stats)
+            return time.time() - t0, st["raysTraced"]
+
+        probe = window(0.06)
+        sec, _ = run_port(probe, False)
+        rect = window(min(1.0, 0.06 * (min(budget_seconds, 30.0) / max(sec, 1e-3)) ** 0.5))
+        _, rays = run_port(rect, True)        # counting pass (not timed)
+        port_sec, _ = run_port(rect, False)   # timed pass without counters
+        return dict(value=rays / port_sec / 1e6, unit="Mray/s", cores=cores, kind="port",
+                    sample=f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image at {spp} spp, depth cap {max_depth}: "
+                           f"{rays} rays in {port_sec:.2f} s on {cores} threads (oracle port; oracle/_ref/ref_path is not built)")
+    probe = window(0.08)
+    _, pst = T.ref_render(desc, spp, probe, seed=seed, threads=cores, stats=False)
+    px = lambda r: (r[2] - r[0] + 1) * (r[3] - r[1] + 1)  # noqa: E731
+    est = pst["seconds"] * W * H / px(probe)
+    rect = (0, 0, W - 1, H - 1) if est <= budget_seconds else window(min(1.0, 0.08 * (budget_seconds / max(pst["seconds"], 1e-3)) ** 0.5))
+    whole = rect == (0, 0, W - 1, H - 1)
+    cpu_img, rst = T.ref_render(desc, spp, rect, seed=seed, threads=cores, stats=False)
+    gpu_img, gst = gpu_render_cap14(rect)
+    same = cpu_img.view(np.uint32) == gpu_img.view(np.uint32)
+    both_nan = np.isnan(cpu_img) & np.isnan(gpu_img)  # (a NaN's sign and payload differ between SSE and the GPU)
+    differing = int((~(same | both_nan)).any(axis=2).sum())
+    rays14 = gst["raysTraced"]
+    cpu_rate, gpu_rate = rays14 / rst["seconds"] / 1e6, rays14 / gst["kernelMs"] / 1e3
+    where = f"the whole {W}x{H} frame" if whole else f"window x{rect[0]}..{rect[2]} y{rect[1]}..{rect[3]} of the {W}x{H} image (the whole frame was estimated at {est:.0f} s, budget {budget_seconds:.0f} s)"
+    return dict(value=cpu_rate, unit="Mray/s", cores=cores, kind="reference+glue",
+                sample=f"{where} at {spp} spp, depth cap 14 (the reference's literal): {rays14} rays in {rst['seconds']:.2f} s on {cores} threads by "
+                       "oracle/_ref/ref_path (the reference's compiled path_tracer/bvh/scene/camera/triangle objects + oracle/ref_glue.cpp for surface fetch and texture taps)",
+                same_cap={"max_depth": 14, "pixels": px(rect), "rays": int(rays14), "gpu_value": gpu_rate, "gpu_ms": gst["kernelMs"], "cpu_value": cpu_rate,
+                          "cpu_seconds": rst["seconds"], "gpu_over_cpu": gpu_rate / cpu_rate,
+                          "note": "GPU and CPU trace the same pixels at the same depth cap with the same per-pixel seeds"},
+                image_check=("GPU image == compiled reference's image, bit for bit" if differing == 0 else f"MISMATCH: {differing} pixels differ") +
+                            f" ({px(rect)} pixels)")
 
 
 def main():
@@ -165,7 +183,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=0)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=120.0, help="budget of the CPU leg: the whole frame when a probe says it fits, else a window")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line: whatever libraries print there while the run lasts (RCCL's version banner, for one) goes to
@@ -317,22 +335,17 @@ def main():
                          "algorithmic_bytes_by_role": algorithmic_split(ct)},
         }
         if not args.no_cpu_baseline and world == 1:
-            try:
-                cb = cpu_baseline(scene, camera, exposure, spp, depth, args.seed, args.cpu_seconds)
-                if cb.get("kind") == "reference" and depth != 14:
-                    # The compiled reference only knows its literal depth cap of 14 (path_tracer.cpp:124).  So that ONE pair of
-                    # figures is the same algorithm at the same cap, the GPU renders the whole frame once more at cap 14:
-                    tracer.max_depth = 14
-                    tracer.render_async(0, 0, W - 1, H - 1, spp, d_rgb=fb.data_ptr(), stream=stream, exposure=exposure)
-                    torch.cuda.synchronize()
-                    s14 = tracer.stats()
+            def gpu_render_cap14(rect):
+                tracer.max_depth = 14
+                try:
+                    img = tracer.trace_block(*rect, spp, exposure=exposure)
+                    return img, tracer.last_stats
+                finally:
                     tracer.max_depth = depth
-                    cb["same_cap"] = {"max_depth": 14, "gpu_value": s14["raysTraced"] / s14["kernelMs"] / 1e3, "cpu_value": cb["value"],
-                                      "gpu_over_cpu": s14["raysTraced"] / s14["kernelMs"] / 1e3 / cb["value"],
-                                      "note": "GPU: whole frame at depth cap 14; CPU: the compiled reference on the window of `sample`"}
-                out["cpu_baseline"] = cb
+            try:
+                out["cpu_baseline"] = cpu_baseline(scene, camera, exposure, spp, depth, args.seed, args.cpu_seconds, gpu_render_cap14)
             except Exception as e:  # the baseline is a report, never the product
-                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "Mray/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.barrier()

@@ -18,8 +18,11 @@ SOURCES = [
     "host/prt_models.cpp",
     "host/prt_host_capi.cpp",
 ]
-HEADERS = ["prt_internal.h", "prt_device.h", "prt_devmath.h", "host/prt.h", "host/cornell_data.inc", "../../include/prt_hip.h",
-           "../../include/prt_host.h", "../../include/prt_hip_test.h"]
+# every header under csrc/ (globbed: a new header can never be forgotten here) plus the interface headers: needs_build() and
+# source_sha16() both derive from these lists, so a stale library can neither be loaded silently nor stamp a measurement
+KERNEL_HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
+HEADERS = KERNEL_HEADERS + ["host/prt.h", "host/cornell_data.inc", "../../include/prt_hip.h", "../../include/prt_host.h",
+                            "../../include/prt_hip_test.h"]
 
 # -ffp-contract=off: the reference's object code has no FMA, and results must match it bit for bit.
 # No fast-math; HIP's default correctly-rounded f32 divide/sqrt is kept.
@@ -64,7 +67,7 @@ def source_sha16():
     a committed counter summary was taken with the code it is running."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(["prt_kernels.hip", "prt_gather.hip", "prt_bvh_build.hip", "prt_frame.h", "prt_device.h", "prt_devmath.h", "prt_internal.h"]):
+    for name in sorted([s for s in SOURCES if s.endswith(".hip")] + KERNEL_HEADERS):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

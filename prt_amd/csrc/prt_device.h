@@ -112,6 +112,7 @@ __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 // slower path through the address-space check; these helpers state the address space at the access.
 #define PRT_AS1 __attribute__((address_space(1)))
 typedef float prt_f4 __attribute__((ext_vector_type(4)));
+typedef float prt_f3 __attribute__((ext_vector_type(3)));
 typedef uint32_t prt_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t prt_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 gld4(const float4* p)
@@ -432,6 +433,7 @@ struct StackT {
     uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
     uint32_t spillStride;
     const lds_f4* hot; // the block's LDS copy of DevScene::hotNodes, or NULL
+    lds_u32* coop;     // the WAVE's 64-word pair table of the cooperative leaf rounds (tracer_leaf_coop)
     __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
         if (e < NLDS) ldsRef[e * PRT_BLOCK] = ref;
@@ -788,6 +790,145 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 #endif
 }
 
+// ---------------------------------------------------------------------------- cooperative leaf rounds
+// The reference's leaf shape for one ray is "1 ray x 8 triangles" (intersectSingleRay, bvh.cpp:302-368): all triangles of the
+// leaf against the hit.t of the leaf's ENTRY, then the accepted candidates in ascending triangle order with a strict
+// `nearestT > t`.  A wave does the same across its lanes: every (ray, triangle) pair of the lanes that stand on a leaf gets a
+// lane of its own -- pairs are numbered by an exclusive prefix sum of the leaves' triangle counts (four ballots: counts are
+// 1..8), a 64-word table in LDS tells pair p its triangle and its owner lane, the owner's ray constants arrive by
+// ds_bpermute -- so a leaf costs its ray ONE round instead of one round per two triangles, and that round runs at full width.
+// The owners then read the wave's ballot of accepted pairs: bits [prefix, prefix + count) are theirs, in triangle order.
+//   nearest hit: the set bits are consumed in ascending order with `t < hit.t` -- candidates were admitted against the entry
+//                hit.t, so this is exactly the reference's loop (and the packet branch's per-triangle select, bvh.cpp:376-424,
+//                which admits against the running hit.t: the same set of updates);
+//   any hit:     a set bit means occluded.
+// The alpha test of a candidate is a function of (triangle, barycentrics) alone; it is evaluated by the pair's lane.
+// Leaves that do not fit into the 64 pairs of this round keep their lanes waiting for the next one.
+#ifndef PRT_COOP_LEAF
+#define PRT_COOP_LEAF 1
+#endif
+#ifndef PRT_COOP_MIN
+#define PRT_COOP_MIN 9u // leaf lanes that make a round a leaf round whatever the node lanes (9 leaves of 6 = 54 pairs)
+#endif
+#ifndef PRT_COOP_WEIGHT
+#define PRT_COOP_WEIGHT 4u // ... or when leaf lanes x this many >= node lanes
+#endif
+#define PRT_COOP_TRI_BITS 26 // a table word = triangle index | owner lane << 26
+
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+#define PRT_COOP_STRIDE 72u // words of LDS per wave: 64 table words + a dump word (lanes that write nothing this round)
+#define PRT_COOP_TRI_MASK ((1u << PRT_COOP_TRI_BITS) - 1u)
+__device__ __forceinline__ float bperm(int byteAddr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byteAddr, __float_as_int(v))); }
+__device__ __forceinline__ uint32_t bperm(int byteAddr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(byteAddr, (int)v); }
+
+template <int MODE, class STK>
+__device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, bool onLeaf, const STK& st, Traffic& tr)
+{
+    constexpr bool OCC = (MODE == PRT_MODE_OCC_PACKET || MODE == PRT_MODE_OCC_SINGLE);
+    constexpr bool PACKET = (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET);
+    const uint32_t lane = threadIdx.x & 63u;
+    // ---- pairs: exclusive prefix sum of the triangle counts over the leaf lanes
+    const uint32_t n = onLeaf ? (T.ref & 15u) : 0u;
+    const unsigned long long b0 = __ballot((n & 1u) != 0u), b1 = __ballot((n & 2u) != 0u), b2 = __ballot((n & 4u) != 0u), b3 = __ballot((n & 8u) != 0u);
+    const uint32_t prefix = mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2) + 8u * mbcnt64(b3);
+    const bool take = onLeaf && prefix + n <= 64u; // the prefix sum is monotone: the takers' pairs are 0 .. pairs-1
+    const unsigned long long takeMask = __ballot(take);
+    const uint32_t last = 63u - (uint32_t)__builtin_clzll(takeMask); // (the first leaf lane always takes: n <= 8)
+    const uint32_t pairs = (uint32_t)__builtin_amdgcn_readlane((int)(prefix + n), (int)last);
+    // ---- table: pair p -> (first triangle - prefix) | owner lane << 26, the same word for every pair of a leaf, so that the
+    // eight stores need no predicate: store i goes to entry min(i, n - 1), lanes that take no part store to the dump word
+    {
+        const uint32_t word = (((T.ref >> 4) - prefix) & PRT_COOP_TRI_MASK) | (lane << PRT_COOP_TRI_BITS);
+        lds_u32* q = st.coop + (take ? prefix : 64u);
+        const uint32_t nm1 = take ? n - 1u : 0u;
+        q[0] = word;
+#pragma unroll
+        for (uint32_t i = 1; i < 8u; i++) q[i < nm1 ? i : nm1] = word;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (no instruction: LDS operations of one wave complete in order)
+    const bool pair = lane < pairs;
+    const uint32_t word = st.coop[lane];
+    const int oaddr = (int)((pair ? (word >> PRT_COOP_TRI_BITS) : lane) << 2);
+    const uint32_t tri = (word + lane) & PRT_COOP_TRI_MASK;
+    __builtin_amdgcn_sched_barrier(0); // (addresses first: a register of the fetch must not be reused for them while it is in flight)
+    float4 a, b;
+    prt_f3 c;
+    if (pair) {
+        const float4* tp = sc.tris + 3 * (size_t)tri;
+        a = gld4(tp);
+        b = gld4(tp + 1);
+        c = *(const PRT_AS1 prt_f3*)(tp + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0); // the fetch is out before the lane exchanges, which need not wait for it
+    // ---- the owner's ray constants (triangle.cpp:118-119 are per ray: prepare_shear)
+    DevRay r;
+    r.org = mk3(bperm(oaddr, T.r.org.x), bperm(oaddr, T.r.org.y), bperm(oaddr, T.r.org.z));
+    r.shearX = bperm(oaddr, T.r.shearX);
+    r.shearY = bperm(oaddr, T.r.shearY);
+    r.invDz = bperm(oaddr, T.r.invDz);
+    const uint32_t flags = bperm(oaddr, (T.r.swapXZ ? 1u : 0u) | (T.r.swapYZ ? 2u : 0u));
+    const float limit = bperm(oaddr, OCC ? T.maxT : T.hit.t);
+    __builtin_amdgcn_sched_barrier(0);
+    r.swapXZ = (flags & 1u) != 0u;
+    r.swapYZ = (flags & 2u) != 0u;
+    float t = -1.0f, bi = 0.0f, bj = 0.0f, bk = 0.0f;
+    uint32_t primId = 0u;
+    bool cand = false;
+    if (pair) {
+        t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
+        primId = asu(a.w);
+        cand = t >= 0.0001f && t < limit;
+        const uint32_t alphaRef = asu(b.w);
+        if (cand && alphaRef) {
+            const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
+            const float4 u0 = gld4(ap), u1 = gld4(ap + 1);
+            const Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y}; // bvh.cpp:336, 407
+            cand = tex_test_alpha<false>(sc, asu(u1.z), uv, PACKET, tr);
+        }
+    }
+    const unsigned long long acc = __ballot(cand);
+    // ---- owners
+    uint32_t seg = take ? ((uint32_t)(acc >> prefix) & ((1u << n) - 1u)) : 0u;
+    if (OCC) {
+        if (take) {
+            if (seg) {
+                T.occ = true;
+                T.ref = PRT_REF_NONE;
+                T.sp = 0;
+                T.m = sc.bvhCount; // finished
+            } else {
+                T.ref = tracer_pop<MODE, false>(T, st, tr);
+            }
+        }
+    } else {
+        if (acc != 0ull) {
+            for (;;) {
+                const bool more = seg != 0u;
+                if (!__any(more)) break;
+                const int saddr = (int)((more ? prefix + (uint32_t)__builtin_ctz(seg) : lane) << 2);
+                const float t2 = bperm(saddr, t), i2 = bperm(saddr, bi), j2 = bperm(saddr, bj), k2 = bperm(saddr, bk);
+                const uint32_t p2 = bperm(saddr, primId);
+                if (more) {
+                    if (t2 < T.hit.t) {
+                        T.hit.t = t2;
+                        T.hit.i = i2;
+                        T.hit.j = j2;
+                        T.hit.k = k2;
+                        T.hit.primId = p2;
+                        T.hit.meshId = T.m;
+                    }
+                    seg &= seg - 1u;
+                }
+            }
+        }
+        if (take) T.ref = tracer_pop<MODE, false>(T, st, tr);
+    }
+}
+
 __device__ __forceinline__ bool ref_is_internal(uint32_t ref) { return !(ref & PRT_REF_LEAF); }
 __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & PRT_REF_LEAF) && ref != PRT_REF_NONE; }
 
@@ -802,7 +943,9 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
         const bool onLeaf = active && ref_is_leaf(T.ref);
         const uint32_t nNode = (uint32_t)__popcll(__ballot(onNode)), nLeaf = (uint32_t)__popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0u) break;
-        const bool doNode = nNode >= nLeaf; // weighting either side, or staying with one kind while it has 16-32 lanes, measured slower
+        // Which kind steps.  Serial leaf steps (counting build): the larger group.  Cooperative leaf rounds: a leaf lane stands for
+        // about six pair lanes, so leaves wait until a round's worth of pairs has gathered or few lanes are left on nodes.
+        const bool doNode = (PRT_COOP_LEAF && !COUNT) ? (nLeaf == 0u || (nLeaf < PRT_COOP_MIN && nLeaf * PRT_COOP_WEIGHT < nNode)) : nNode >= nLeaf;
 #ifdef PRT_PAD_VALU
         { // sensitivity probe of tools/build_variants.py: PRT_PAD_VALU extra vector instructions per round (never in the product)
             float pad = T.maxT;
@@ -823,6 +966,8 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
 #endif
         if (doNode) {
             if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+        } else if (PRT_COOP_LEAF && !COUNT) {
+            tracer_leaf_coop<MODE>(sc, T, onLeaf, st, tr);
         } else {
             if (onLeaf) tracer_tri<MODE, COUNT>(sc, T, st, tr);
         }

@@ -101,6 +101,7 @@ struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
     uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
     float hot[PRT_HOT_LDS ? PRT_HOT_NODES * 16 : 4]; // DevScene::hotNodes (16-byte aligned: read with ds_read_b128)
+    uint32_t coop[(PRT_BLOCK / 64) * PRT_COOP_STRIDE]; // per wave: the pair table of the cooperative leaf rounds (prt_device.h)
     uint32_t pending[PRT_POOL_GROUPS];
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
@@ -584,7 +585,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const uint32_t slotBase = blockIdx.x * PRT_POOL_SLOTS;
     const uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
     const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid),
-                          A.spillStride, PRT_HOT_LDS ? (const lds_f4*)&B->hot[0] : nullptr};
+                          A.spillStride, PRT_HOT_LDS ? (const lds_f4*)&B->hot[0] : nullptr, (lds_u32*)&B->coop[(tid >> 6) * PRT_COOP_STRIDE]};
     const DevScene& sc = A.sc;
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
     const Vec3 sceneLight = mk3(sc.lightDir[0], sc.lightDir[1], sc.lightDir[2]);

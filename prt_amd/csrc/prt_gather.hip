@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -111,9 +112,20 @@ Rccl& rccl()
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
+        // PRT_RCCL_LIB names the library to bind instead (read once, never written): a host with its own RCCL build, or the
+        // test suite's stand-in whose "ranks" are threads of one process (tests/fake_rccl.cpp) -- the only way the > 1-rank
+        // branch below can run on a one-GPU box, where RCCL itself refuses two ranks on one device.
+        const char* override = getenv("PRT_RCCL_LIB");
+        if (override && *override) {
+            R.handle = dlopen(override, RTLD_NOW | RTLD_LOCAL);
+            if (!R.handle) {
+                R.why = std::string("PRT_RCCL_LIB=") + override + ": " + (dlerror() ? dlerror() : "?");
+                return;
+            }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            R.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (R.handle) break;
+            R.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!R.handle) {
             R.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
@@ -142,6 +154,17 @@ Rccl& rccl()
     do {                                                                                                      \
         int r_ = (call);                                                                                      \
         if (r_ != 0) return prt_fail(PRT_HIP_ECOMM, std::string(#call) + ": " + (R).GetErrorString(r_));      \
+    } while (0)
+
+// Inside ncclGroupStart .. ncclGroupEnd: a failing call must not leave the group open (every later RCCL call of this thread
+// would be queued into it and never run) -- close it, then report the FIRST error.
+#define RCCL_TRY_IN_GROUP(R, call)                                                                            \
+    do {                                                                                                      \
+        int r_ = (call);                                                                                      \
+        if (r_ != 0) {                                                                                        \
+            (void)(R).GroupEnd();                                                                             \
+            return prt_fail(PRT_HIP_ECOMM, std::string(#call) + ": " + (R).GetErrorString(r_));               \
+        }                                                                                                     \
     } while (0)
 
 int need_rccl(Rccl** out)
@@ -273,7 +296,7 @@ int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
             if ((rc = ensure_floats(&c->packBuf, &c->packFloats, mine * tileFloats))) return rc;
             launch_pack(false, d_rgb, c->packBuf, W, H, T, me, n, mine, s);
             RCCL_TRY(*R, R->GroupStart());
-            if (mine) RCCL_TRY(*R, R->Send(c->packBuf, mine * tileFloats, kNcclFloat, root, c->comm, s));
+            if (mine) RCCL_TRY_IN_GROUP(*R, R->Send(c->packBuf, mine * tileFloats, kNcclFloat, root, c->comm, s));
             RCCL_TRY(*R, R->GroupEnd());
         } else {
             // staged tiles of rank r start at off[r]; the root's own tiles are already where they belong
@@ -283,7 +306,7 @@ int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
             RCCL_TRY(*R, R->GroupStart());
             for (uint32_t r = 0; r < n; r++) {
                 const size_t cnt = off[r + 1] - off[r];
-                if (r != me && cnt) RCCL_TRY(*R, R->Recv(c->stageBuf + off[r], cnt, kNcclFloat, (int)r, c->comm, s));
+                if (r != me && cnt) RCCL_TRY_IN_GROUP(*R, R->Recv(c->stageBuf + off[r], cnt, kNcclFloat, (int)r, c->comm, s));
             }
             RCCL_TRY(*R, R->GroupEnd());
             for (uint32_t r = 0; r < n; r++)

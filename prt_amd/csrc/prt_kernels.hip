@@ -201,7 +201,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
     __shared__ uint32_t ldsRef[PRT_STACK_LDS * PRT_BLOCK];
     __shared__ float ldsT[PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
+    __shared__ uint32_t coopTbl[(PRT_BLOCK / 64) * PRT_COOP_STRIDE];
+    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr,
+                                   (lds_u32*)&coopTbl[(tid >> 6) * PRT_COOP_STRIDE]};
     GbufSrc src{&A};
     Traffic tr{};
     uint32_t overflow = 0;
@@ -266,7 +268,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
     __shared__ uint32_t ldsRef[NLDS * PRT_BLOCK];
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
-    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr};
+    __shared__ uint32_t coopTbl[(PRT_BLOCK / 64) * PRT_COOP_STRIDE];
+    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr,
+                          (lds_u32*)&coopTbl[(tid >> 6) * PRT_COOP_STRIDE]};
     ArraySrc src{&A, MODE};
     Traffic tr{};
     uint32_t overflow = 0;
@@ -556,7 +560,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                     return fail(PRT_HIP_EINVAL, "bad leaf range");
                 }
             }
-            if ((size_t)triBase + md.primCount >= (1u << 27) || nextWide >= (1u << 30)) return fail(PRT_HIP_EINVAL, "scene too large for 32-bit child references");
+            if ((size_t)triBase + md.primCount >= (1u << PRT_COOP_TRI_BITS) || nextWide >= (1u << 30)) return fail(PRT_HIP_EINVAL, "scene too large for 32-bit child references"); // (a pair-table word holds a triangle index in 26 bits)
             auto refOf = [&](uint32_t i) -> uint32_t {
                 const prt_bvh_node& n = md.nodes[i];
                 if (n.primCount == 0xf) return wideIndex[i];

@@ -569,3 +569,17 @@ def teapot_product_mesh():
                                   texcoords=m.texcoords)
     pm.transform(0.005, (-0.5, 0.0, 0.5))
     return pm
+
+
+def build_fake_rccl():
+    """tests/fake_rccl.cpp -> tests/_build/libfake_rccl.so (host C++ against libamdhip64; rebuilt when the source is newer)."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, out = os.path.join(here, "fake_rccl.cpp"), os.path.join(here, "_build", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", src, "-o", out + ".tmp",
+                               f"-L{rocm}/lib", "-lamdhip64", "-pthread", f"-Wl,-rpath,{rocm}/lib"])
+        os.replace(out + ".tmp", out)
+    return out

@@ -636,6 +636,24 @@ def test_rccl_gather_single_rank_communicator(tracer, c1):
         t.close()
 
 
+def test_rccl_gather_two_and_three_ranks_through_the_standin():
+    """The > 1-rank branch of prt_hip_gather_rccl (prt_gather.hip: pack on the owners, the root's staging offset table, grouped
+    ncclSend / ncclRecv, one de-interleave per peer) EXECUTED on this one-GPU box: PRT_RCCL_LIB points the product at
+    tests/fake_rccl.cpp, a stand-in whose ranks are threads of one process with a context each and whose send/recv rendezvous
+    and move the bytes with hipMemcpyAsync, refusing a receive whose size differs from its send.  2 and 3 ranks, ragged images,
+    roots 0 / 1 / 2, more ranks than tiles, tile sizes 8 / 16 / 32, each gather twice: the root's image must equal the one-GPU
+    image bit for bit and the bytes moved must be exactly the peers' tiles.  Then a failing ncclSend and a failing ncclRecv
+    inside the group: the error is reported, the group is closed, the communicator still works.  (The real RCCL is exercised by
+    test_rccl_gather_single_rank_communicator; a real multi-GPU run is the driver's SCALE step.)"""
+    import subprocess
+    import sys
+    fake = T.build_fake_rccl()
+    env = dict(os.environ, PRT_RCCL_LIB=fake)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_threads_child.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK 6" in out.stdout, out.stdout + out.stderr
+
+
 def test_full_size_c3_properties(tracer):
     """BASELINE config 3 as bench.py runs it (Sponza-class stand-in, 262 k triangles, 1920x1080, 64 spp, depth 8), checked
     through size-independent properties: repeatable, independent of how the image is cut into launches and ranks

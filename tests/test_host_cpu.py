@@ -6,6 +6,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -43,6 +44,26 @@ def test_library_exports_every_declared_symbol(L):
         assert hasattr(TL, name), name
     syms = subprocess.check_output(["nm", "-D", "--defined-only", prt_amd.LIB_PATH]).decode()
     assert "rays_kernel" not in syms and "leaf_kernel" not in syms and "prt_hip_test" not in syms
+
+
+def test_rccl_standin_covers_every_symbol_the_product_binds(tmp_path):
+    """tests/fake_rccl.cpp (the thread-rank stand-in behind the GPU suite's > 1-rank gather test) must define every ncclXxx the
+    product looks up with dlsym (prt_gather.hip), or the product would refuse it on the GPU box; and a PRT_RCCL_LIB that cannot
+    be loaded is an error message, never a silent fall-back to another library."""
+    src = open(os.path.join(T.ROOT, "prt_amd", "csrc", "prt_gather.hip")).read()
+    bound = set(re.findall(r'sym\("(nccl[A-Za-z]+)"\)', src))
+    assert len(bound) == 10, bound
+    fake = T.build_fake_rccl()
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", fake]).decode()
+    for name in bound:
+        assert f" T {name}" in syms, name
+    code = ("import prt_amd, ctypes as C; L = prt_amd.lib(); b = C.create_string_buffer(128); rc = L.prt_hip_comm_unique_id(b); "
+            "print(rc, L.prt_hip_last_error().decode())")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PRT_RCCL_LIB=str(tmp_path / "nowhere.so"), PYTHONPATH=T.ROOT),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PRT_RCCL_LIB=" in out.stdout and not out.stdout.startswith("0 "), out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PRT_RCCL_LIB=fake, PYTHONPATH=T.ROOT), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("0 "), out.stdout + out.stderr  # the stand-in's ncclGetUniqueId answered
 
 
 def test_no_gpu_means_loud_failure(L):
