@@ -27,7 +27,7 @@
 #define PRT_TRI2 1 // a leaf step tests two triangles (one: 569 ms against 547 on C3)
 #endif
 #ifndef PRT_IDLE_BREAK
-#define PRT_IDLE_BREAK 8 // lanes without a node or triangle to step on that send the wave back to the refill point
+#define PRT_IDLE_BREAK 24 // finished rays that send the wave back to its refill point (a refill turn costs about four rounds: 8 -> 463, 16 -> 424, 24-32 -> 412-422 ms on C3)
 #endif
 // ---------------------------------------------------------------------------- device scene
 // wnodes: 4 x float4 (64 B) per INTERNAL node, (lo, hi) pairs per axis so that the slab arithmetic runs on packed
@@ -179,6 +179,7 @@ struct Traffic {
     // tallies of the profile build: rounds of either kind and the lanes that took part in them (wave-uniform); stack pops
     // and those that came from the spill area in HBM (per lane)
     unsigned long long pNodeRounds, pNodeLanes, pLeafRounds, pLeafLanes, pTri2Lanes, pPops, pDeepPops;
+    unsigned long long pNodeWaitLeaf, pNodeDone, pNodeNoRay, pLeafWaitNode, pLeafDone, pLeafNoRay, pLeafUpdates; // lanes that sit a round out, by reason (wave-uniform)
 #endif
 };
 
@@ -813,6 +814,9 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 #ifndef PRT_COOP_WEIGHT
 #define PRT_COOP_WEIGHT 4u // ... or when leaf lanes x this many >= node lanes
 #endif
+#ifndef PRT_COOP_PREPOP
+#define PRT_COOP_PREPOP 1
+#endif
 #define PRT_COOP_TRI_BITS 26 // a table word = triangle index | owner lane << 26
 
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m)
@@ -839,6 +843,9 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     const unsigned long long takeMask = __ballot(take);
     const uint32_t last = 63u - (uint32_t)__builtin_clzll(takeMask); // (the first leaf lane always takes: n <= 8)
     const uint32_t pairs = (uint32_t)__builtin_amdgcn_readlane((int)(prefix + n), (int)last);
+#ifdef PRT_PROFILE
+    tr.pTri2Lanes += pairs;
+#endif
     // ---- table: pair p -> (first triangle - prefix) | owner lane << 26, the same word for every pair of a leaf, so that the
     // eight stores need no predicate: store i goes to entry min(i, n - 1), lanes that take no part store to the dump word
     {
@@ -852,6 +859,11 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (no instruction: LDS operations of one wave complete in order)
     const bool pair = lane < pairs;
     const uint32_t word = st.coop[lane];
+#if PRT_COOP_PREPOP
+    // the entry a taker pops when its leaf is done is already known: read it beside the table, not after the round
+    const int popAt = T.sp > 0 ? T.sp - 1 : 0;
+    uint32_t popped = st.ldsRef[(popAt < STK::kLds ? popAt : 0) * PRT_BLOCK];
+#endif
     const int oaddr = (int)((pair ? (word >> PRT_COOP_TRI_BITS) : lane) << 2);
     const uint32_t tri = (word + lane) & PRT_COOP_TRI_MASK;
     __builtin_amdgcn_sched_barrier(0); // (addresses first: a register of the fetch must not be reused for them while it is in flight)
@@ -901,12 +913,24 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
                 T.sp = 0;
                 T.m = sc.bvhCount; // finished
             } else {
+#if PRT_COOP_PREPOP
+                if (T.sp == 0) T.ref = PRT_REF_NONE;
+                else {
+                    if (popAt >= STK::kLds) popped = st.get(popAt);
+                    T.sp = popAt;
+                    T.ref = popped;
+                }
+#else
                 T.ref = tracer_pop<MODE, false>(T, st, tr);
+#endif
             }
         }
     } else {
         if (acc != 0ull) {
             for (;;) {
+#ifdef PRT_PROFILE
+                tr.pLeafUpdates++;
+#endif
                 const bool more = seg != 0u;
                 if (!__any(more)) break;
                 const int saddr = (int)((more ? prefix + (uint32_t)__builtin_ctz(seg) : lane) << 2);
@@ -925,7 +949,19 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
                 }
             }
         }
+#if PRT_COOP_PREPOP
+        if (take) {
+            if (MODE == PRT_MODE_PACKET) T.ref = tracer_pop<MODE, false>(T, st, tr); // (its pop tests the entry distance against the new hit.t)
+            else if (T.sp == 0) T.ref = PRT_REF_NONE;
+            else {
+                if (popAt >= STK::kLds) popped = st.get(popAt);
+                T.sp = popAt;
+                T.ref = popped;
+            }
+        }
+#else
         if (take) T.ref = tracer_pop<MODE, false>(T, st, tr);
+#endif
     }
 }
 
@@ -958,10 +994,16 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
         if (doNode) {
             tr.pNodeRounds++;
             tr.pNodeLanes += nNode;
+            tr.pNodeWaitLeaf += nLeaf;
+            tr.pNodeDone += (unsigned long long)__popcll(__ballot(active && T.ref == PRT_REF_NONE));
+            tr.pNodeNoRay += (unsigned long long)__popcll(__ballot(!active));
         } else {
             tr.pLeafRounds++;
             tr.pLeafLanes += nLeaf;
-            tr.pTri2Lanes += (unsigned long long)__popcll(__ballot(onLeaf && (T.ref & 15u) > 1u));
+            tr.pLeafWaitNode += nNode;
+            tr.pLeafDone += (unsigned long long)__popcll(__ballot(active && T.ref == PRT_REF_NONE));
+            tr.pLeafNoRay += (unsigned long long)__popcll(__ballot(!active));
+            if (!(PRT_COOP_LEAF && !COUNT)) tr.pTri2Lanes += (unsigned long long)__popcll(__ballot(onLeaf && (T.ref & 15u) > 1u));
         }
 #endif
         if (doNode) {

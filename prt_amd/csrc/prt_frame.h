@@ -608,15 +608,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pRefills = 0, pRefillLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
-        // ---- 1. finished rays of the previous turn: their stores are complete -> tell the group
-        if (__any(sig != PRT_NONE)) {
-            wg_release();
-            if (sig != PRT_NONE) {
-                if (lds_sub(&B->pending[sig], 1u) == 1u) lds_add(&B->ready, 1u);
-                sig = PRT_NONE;
-            }
-        }
-        // ---- 2. refill.  The wave takes PRT_CLAIM entries of the queue at a time and hands them to its lanes as they come
+        // ---- 1. refill.  The wave takes PRT_CLAIM entries of the queue at a time and hands them to its lanes as they come
         // free: consecutive entries are rays of neighbouring pixels at the same bounce, and lanes that walk the same part of
         // the tree step together.  The entries are READ when they are claimed and wait in registers (held[]): the ring's
         // capacity argument -- at most one ray per slot and mode is out -- only holds for entries consumed in order.
@@ -723,28 +715,42 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
                 active = true;
             }
         }
+        // ---- 2. rays that finished in the previous turn: their result stores were issued before this turn's refill loads, which
+        // the refill has waited for (vector memory operations of a wave retire in order), so the release below is free -> tell the group
+        if (__any(sig != PRT_NONE)) {
+            wg_release();
+            if (sig != PRT_NONE) {
+                if (lds_sub(&B->pending[sig], 1u) == 1u) lds_add(&B->ready, 1u);
+                sig = PRT_NONE;
+            }
+        }
         if (!__any(active)) break;
 #ifdef PRT_PROFILE
         pTurns++;
         pLanes += (unsigned long long)__popcll(__ballot(active));
 #endif
-        // ---- 3. rays that have left their last BVH
-        if (active && T.ref == PRT_REF_NONE) {
-            if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
-                const uint32_t gs = slotBase + owner;
-                if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
-                    if (T.hit.t == T.maxT) T.hit.t = -1.0f; // setMissForMaxT, scene.cpp:62
-                    nt_store4(&A.hitA[gs], make_float4(T.hit.t, T.hit.i, T.hit.j, T.hit.k));
-                    gst2u(&A.hitB[gs], make_uint2(T.hit.primId, T.hit.meshId));
-                } else {
-                    gst(&A.occl[gs], T.occ ? 1u : 0u);
+        // ---- 3. new rays enter their first BVH (one that misses every root box is finished at once), 4. step, 5. rays that have
+        // left their last BVH store their result and give the lane up NOW, so that the next turn's refill -- the next thing the
+        // wave does -- hands it a new ray; retiring them behind the refill (as the first version of this loop did) left every
+        // such lane empty for a whole step phase: 18 of 64 lanes in a scatter-ray node round (profiles/r03_experiments.txt).
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            if (active && T.ref == PRT_REF_NONE) {
+                if (!tracer_next_bvh<MODE, COUNT>(sc, T, tr)) {
+                    const uint32_t gs = slotBase + owner;
+                    if (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_SINGLE) {
+                        if (T.hit.t == T.maxT) T.hit.t = -1.0f; // setMissForMaxT, scene.cpp:62
+                        nt_store4(&A.hitA[gs], make_float4(T.hit.t, T.hit.i, T.hit.j, T.hit.k));
+                        gst2u(&A.hitB[gs], make_uint2(T.hit.primId, T.hit.meshId));
+                    } else {
+                        gst(&A.occl[gs], T.occ ? 1u : 0u);
+                    }
+                    sig = owner >> 3;
+                    active = false;
                 }
-                sig = owner >> 3;
-                active = false;
             }
+            if (pass == 0) trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
         }
-        // ---- 4. step
-        trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
     }
     if (overflow) lds_st(&B->overflow, 1u);
     if (COUNT) {
@@ -783,6 +789,13 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[34 + MODE * 8], tr.pLeafRounds);
         atomicAdd(&C[35 + MODE * 8], tr.pLeafLanes);
         atomicAdd(&C[36 + MODE * 8], tr.pTri2Lanes);
+        atomicAdd(&C[64 + MODE * 8], tr.pNodeWaitLeaf);
+        atomicAdd(&C[65 + MODE * 8], tr.pNodeDone);
+        atomicAdd(&C[66 + MODE * 8], tr.pNodeNoRay);
+        atomicAdd(&C[67 + MODE * 8], tr.pLeafWaitNode);
+        atomicAdd(&C[68 + MODE * 8], tr.pLeafDone);
+        atomicAdd(&C[69 + MODE * 8], tr.pLeafNoRay);
+        atomicAdd(&C[70 + MODE * 8], tr.pLeafUpdates);
         atomicAdd(&C[37 + MODE * 8], pRefillLanes);
         atomicAdd(&C[38 + MODE * 8], pRefills);
         atomicAdd(&C[16 + MODE * 3], pTurns);

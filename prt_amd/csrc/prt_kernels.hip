@@ -1037,9 +1037,16 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
                     h[18 + 3 * m] * 1024.0 / (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1));
         for (int m = 0; m < 4; m++) {
             const unsigned long long* q = h + 32 + 8 * m;
-            fprintf(stderr, "  mode %d rounds: node %.1f M with %.1f lanes, leaf %.1f M with %.1f lanes (%.1f on a second triangle); refills %.1f M with %.1f lanes\n", m,
+            fprintf(stderr, "  mode %d rounds: node %.1f M with %.1f lanes, leaf %.1f M with %.1f lanes on a leaf (%.1f pair lanes working; serial build: lanes on a second triangle); refills %.1f M with %.1f lanes\n", m,
                     q[0] / 1e6, (double)q[1] / (double)(q[0] ? q[0] : 1), q[2] / 1e6, (double)q[3] / (double)(q[2] ? q[2] : 1),
                     (double)q[4] / (double)(q[2] ? q[2] : 1), q[6] / 1e6, (double)q[5] / (double)(q[6] ? q[6] : 1));
+        }
+        for (int m = 0; m < 4; m++) {
+            const unsigned long long* q = h + 32 + 8 * m;
+            const unsigned long long* w = h + 64 + 8 * m;
+            const double nr = (double)(q[0] ? q[0] : 1), lr = (double)(q[2] ? q[2] : 1);
+            fprintf(stderr, "  mode %d lanes sitting out: node rounds %.1f on a leaf, %.1f finished, %.1f without a ray; leaf rounds %.1f on a node, %.1f finished, %.1f without a ray; %.2f hit-update turns per leaf round\n",
+                    m, w[0] / nr, w[1] / nr, w[2] / nr, w[3] / lr, w[4] / lr, w[5] / lr, w[6] / lr);
         }
         fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));

@@ -44,6 +44,7 @@ def in_threads(fns):
 
 def main():
     fake = C.CDLL(os.environ["PRT_RCCL_LIB"])  # the same loaded object the product binds
+    hip = C.CDLL("libamdhip64.so")
     fake.fake_rccl_counts.argtypes = [C.POINTER(C.c_uint64)] * 3
     cases = 0
     # (width, height, ranks, root, tile): ragged right/bottom tiles, a root that is not rank 0, more ranks than tiles, another tile size
@@ -62,6 +63,9 @@ def main():
                 t.set_camera(camera)
                 t.comm_init(uid, i, n)
             for rep in range(2):  # twice: the staging buffers of the first gather are reused by the second
+                fbp = ranks[root]._L.prt_hip_framebuffer(ranks[root]._ctx)  # device pointer, or None before the first render
+                if fbp:  # forget the first gather's image
+                    assert hip.hipMemset(C.c_void_p(fbp), 0, C.c_size_t(W * H * 12)) == 0 and hip.hipDeviceSynchronize() == 0
                 for i, t in enumerate(ranks):
                     t.render_async(0, 0, W - 1, H - 1, 8, rank=i, nranks=n, tile=tile)
                 own = download(ranks[root], W, H)
