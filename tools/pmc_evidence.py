@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc passes of one C3 frame (tools/pmc_pass.sh, one counter block per pass) into ONE tracked JSON:
+"""Summarise the rocprofv3 --pmc passes of one frame (tools/pmc_frame.py: C3, C4 or one rank's share of C5) (tools/pmc_pass.sh, one counter block per pass) into ONE tracked JSON:
 what bounds the frame kernel, with every figure DESIGN.md quotes.  Conventions (MI355X_MICROARCH.md):
   * SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, summed over waves; SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU =
     lanes active per vector instruction;
@@ -20,17 +20,18 @@ for suffix in ("sq", "sq2", "tcp", "tcc", "fetch", "write", "ta", "ta2", "grbm")
     for r in csv.DictReader(open(path)):
         if "frame_kernel" in r["Kernel_Name"]:
             C[r["Counter_Name"]] = C.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    m = re.search(r"frame kernel ms ([0-9.]+) rays (\d+)", open(f"{prefix}_{suffix}/log.txt").read())
+    m = re.search(r"frame kernel ms ([0-9.]+) rays (\d+)(?: workload (\S+) (\S+))?", open(f"{prefix}_{suffix}/log.txt").read())
     if m:
         ms.append(float(m.group(1)))
         rays = int(m.group(2))
+        workload, frame = (m.group(3), m.group(4)) if m.group(3) else ("c3_sponza_standin", "1920x1080,64spp,depth8")
 kernel_ms = sorted(ms)[len(ms) // 2]
 g = lambda k: C.get(k, float("nan"))
 clock = g("GRBM_GUI_ACTIVE") / 8 / (kernel_ms * 1e-3)
 fetch, write = g("FETCH_SIZE") * 1024, g("WRITE_SIZE") * 1024
 import prt_amd
 d = {
-    "workload": "c3_sponza_standin", "frame": "1920x1080, 64 spp, depth 8, one GPU", "kernel": "frame_kernel<false, false>",
+    "workload": workload, "frame": frame + ", one GPU", "kernel": "frame_kernel<false, false>",
     "source_sha16": prt_amd.source_sha16(), "kernel_ms_under_profiler_median": kernel_ms, "rays_per_frame": rays,
     "counters_raw": {k: C[k] for k in sorted(C)},
     "derived": {
@@ -39,6 +40,9 @@ d = {
         "wave_time_issue_stall_frac (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
         "wave_time_issuing_frac (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)": g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"),
         "valu_instructions_per_ray": g("SQ_INSTS_VALU") / rays,
+        "salu_instructions_per_ray": g("SQ_INSTS_SALU") / rays,
+        # one wave64 vector instruction occupies a SIMD for 3.07 cycles with 8 waves resident (profiles/r02_valu_rate.txt); 256 CUs x 4 SIMDs
+        "valu_busy_frac (SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles)": g("SQ_INSTS_VALU") * 3.07 / 1024.0 / (clock * kernel_ms * 1e-3),
         "vmem_read_instructions_per_ray": g("SQ_INSTS_VMEM_RD") / rays,
         "effective_clock_GHz": clock / 1e9,
         "ta_busy_frac (TA_BUSY_avr / cycles of the frame)": g("TA_BUSY_avr") / (g("GRBM_GUI_ACTIVE") / 8),

@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 name=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
-timeout -k 10 180 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $out -o run -- python3 $GRAFT_REPO_ROOT/tools/pmc_frame.py > $out/log.txt 2>&1
+timeout -k 10 ${PRT_PMC_TIMEOUT:-180} rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $out -o run -- python3 $GRAFT_REPO_ROOT/tools/pmc_frame.py > $out/log.txt 2>&1
 tail -2 $out/log.txt
