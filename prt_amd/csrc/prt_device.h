@@ -431,19 +431,30 @@ struct StackT {
     static constexpr int kLds = NLDS;
     lds_u32* ldsRef; // &refs[threadIdx.x]
     lds_f32* ldsT;   // &ts[threadIdx.x]
-    uint32_t* spill;  // &spill[globalThread]; [entry][thread], two words per entry
+    // the spill area: [entry][thread of the launch], two words per entry.  Only its (uniform) base is kept; the thread's column
+    // is recomputed where a deep entry is touched -- a per-thread 64-bit pointer held across the step loop was the one value the
+    // register allocator kept in scratch memory there (reloaded on this cold path, profiles/r03_step_loop_isa.txt)
+    uint32_t* spillBase;
     uint32_t spillStride;
     const lds_f4* hot; // the block's LDS copy of DevScene::hotNodes, or NULL
     lds_u32* coop;     // the WAVE's 64-word pair table of the cooperative leaf rounds (tracer_leaf_coop)
+    __device__ __forceinline__ uint32_t* deep(int e, int word) const
+    {
+        // the thread's index, from the LDS address of its stack column -- a value the loop keeps in a register anyway.  The asm is
+        // opaque to the optimiser, which otherwise hoists "block * 256 + thread" out of the step loop and parks it in scratch
+        uint32_t thread;
+        asm volatile("v_lshrrev_b32 %0, 2, %1" : "=v"(thread) : "v"((uint32_t)(uintptr_t)ldsRef - (uint32_t)(uintptr_t)(ldsRef - threadIdx.x)));
+        return spillBase + ((size_t)(2 * (e - NLDS) + word) * spillStride + (blockIdx.x * PRT_BLOCK + thread));
+    }
     __device__ __forceinline__ void put(int e, uint32_t ref) const
     {
         if (e < NLDS) ldsRef[e * PRT_BLOCK] = ref;
-        else gst(&spill[(size_t)(2 * (e - NLDS)) * spillStride], ref);
+        else gst(deep(e, 0), ref);
     }
     __device__ __forceinline__ uint32_t get(int e) const
     {
         uint32_t v = ldsRef[(e < NLDS ? e : 0) * PRT_BLOCK];
-        if (e >= NLDS) v = gld(&spill[(size_t)(2 * (e - NLDS)) * spillStride]);
+        if (e >= NLDS) v = gld(deep(e, 0));
         return v;
     }
     __device__ __forceinline__ void putT(int e, uint32_t ref, float t) const
@@ -452,14 +463,14 @@ struct StackT {
             ldsRef[e * PRT_BLOCK] = ref;
             ldsT[e * PRT_BLOCK] = t;
         } else {
-            gst(&spill[(size_t)(2 * (e - NLDS)) * spillStride], ref);
-            gst(&spill[(size_t)(2 * (e - NLDS) + 1) * spillStride], asu(t));
+            gst(deep(e, 0), ref);
+            gst(deep(e, 1), asu(t));
         }
     }
     __device__ __forceinline__ float getT(int e) const
     {
         float v = ldsT[(e < NLDS ? e : 0) * PRT_BLOCK];
-        if (e >= NLDS) v = asf(gld(&spill[(size_t)(2 * (e - NLDS) + 1) * spillStride]));
+        if (e >= NLDS) v = asf(gld(deep(e, 1)));
         return v;
     }
 };

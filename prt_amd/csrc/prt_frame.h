@@ -584,7 +584,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t slotBase = blockIdx.x * PRT_POOL_SLOTS;
     const uint32_t* blockQ = A.qE + (size_t)blockIdx.x * Q_COUNT * PRT_POOL_SLOTS;
-    const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid),
+    const StackT<NLDS> st{(lds_u32*)&B->stack[tid], (lds_f32*)&B->stack[NLDS * PRT_BLOCK + tid], A.spill,
                           A.spillStride, PRT_HOT_LDS ? (const lds_f4*)&B->hot[0] : nullptr, (lds_u32*)&B->coop[(tid >> 6) * PRT_COOP_STRIDE]};
     const DevScene& sc = A.sc;
     const Vec3 camPos = mk3(A.cam.pos[0], A.cam.pos[1], A.cam.pos[2]);
@@ -606,12 +606,16 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     __builtin_amdgcn_s_setprio(PRT_TRACE_PRIO); // tracing waves sit on dependent loads: they issue first, shading fills in
 #ifdef PRT_PROFILE
     unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pRefills = 0, pRefillLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pTRefill = 0, pTEnter = 0, pTStep = 0;
 #endif
     for (;;) {
         // ---- 1. refill.  The wave takes PRT_CLAIM entries of the queue at a time and hands them to its lanes as they come
         // free: consecutive entries are rays of neighbouring pixels at the same bounce, and lanes that walk the same part of
         // the tree step together.  The entries are READ when they are claimed and wait in registers (held[]): the ring's
         // capacity argument -- at most one ray per slot and mode is out -- only holds for entries consumed in order.
+#ifdef PRT_PROFILE
+        const unsigned long long pTa = __builtin_amdgcn_s_memtime();
+#endif
         const unsigned long long need = __ballot(!active);
         if (need) {
             const uint32_t k = (uint32_t)__popcll(need);
@@ -724,6 +728,10 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
                 sig = PRT_NONE;
             }
         }
+#ifdef PRT_PROFILE
+        const unsigned long long pTb = __builtin_amdgcn_s_memtime();
+        pTRefill += pTb - pTa;
+#endif
         if (!__any(active)) break;
 #ifdef PRT_PROFILE
         pTurns++;
@@ -749,7 +757,14 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
                     active = false;
                 }
             }
+#ifdef PRT_PROFILE
+            const unsigned long long pTc = __builtin_amdgcn_s_memtime();
+            if (pass == 0) pTEnter += pTc - pTb;
+#endif
             if (pass == 0) trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
+#ifdef PRT_PROFILE
+            if (pass == 0) pTStep += __builtin_amdgcn_s_memtime() - pTc;
+#endif
         }
     }
     if (overflow) lds_st(&B->overflow, 1u);
@@ -789,6 +804,9 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[34 + MODE * 8], tr.pLeafRounds);
         atomicAdd(&C[35 + MODE * 8], tr.pLeafLanes);
         atomicAdd(&C[36 + MODE * 8], tr.pTri2Lanes);
+        atomicAdd(&C[96 + MODE * 4], pTRefill >> 10);
+        atomicAdd(&C[97 + MODE * 4], pTEnter >> 10);
+        atomicAdd(&C[98 + MODE * 4], pTStep >> 10);
         atomicAdd(&C[64 + MODE * 8], tr.pNodeWaitLeaf);
         atomicAdd(&C[65 + MODE * 8], tr.pNodeDone);
         atomicAdd(&C[66 + MODE * 8], tr.pNodeNoRay);

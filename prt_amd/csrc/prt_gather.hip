@@ -119,7 +119,8 @@ Rccl& rccl()
         if (override && *override) {
             R.handle = dlopen(override, RTLD_NOW | RTLD_LOCAL);
             if (!R.handle) {
-                R.why = std::string("PRT_RCCL_LIB=") + override + ": " + (dlerror() ? dlerror() : "?");
+                const char* e = dlerror(); // (a second call returns NULL: the first one clears the message)
+                R.why = std::string("PRT_RCCL_LIB=") + override + ": " + (e ? e : "?");
                 return;
             }
         }
@@ -128,7 +129,8 @@ Rccl& rccl()
             R.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!R.handle) {
-            R.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            const char* e = dlerror();
+            R.why = std::string("librccl not found: ") + (e ? e : "?");
             return;
         }
         auto sym = [&](const char* n) {

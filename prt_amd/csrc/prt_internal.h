@@ -12,7 +12,7 @@
 #define PRT_WORK_WORDS 512 // control words of a launch (frame kernel: prt_frame.h PRT_CTRL_CURSORS; claim cursor of the G-buffer kernel)
 #define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
 #ifdef PRT_PROFILE
-#define PRT_STAT_STRIDE 96 // the profile build appends its lane-utilisation counters (words 32..95)
+#define PRT_STAT_STRIDE 128 // the profile build appends its lane-utilisation counters (words 32..127)
 #else
 #define PRT_STAT_STRIDE 32 // 64-bit words per copy (256 B apart)
 #endif

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void gbuffer_kernel(GbufArgs A)
     __shared__ float ldsT[PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     __shared__ uint32_t coopTbl[(PRT_BLOCK / 64) * PRT_COOP_STRIDE];
-    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr,
+    const StackT<PRT_STACK_LDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill, A.spillStride, nullptr,
                                    (lds_u32*)&coopTbl[(tid >> 6) * PRT_COOP_STRIDE]};
     GbufSrc src{&A};
     Traffic tr{};
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void rays_kernel(RaysArgs A)
     __shared__ float ldsT[(MODE == PRT_MODE_PACKET ? NLDS : 1) * PRT_BLOCK];
     const uint32_t tid = threadIdx.x;
     __shared__ uint32_t coopTbl[(PRT_BLOCK / 64) * PRT_COOP_STRIDE];
-    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill + ((size_t)blockIdx.x * PRT_BLOCK + tid), A.spillStride, nullptr,
+    const StackT<NLDS> st{(lds_u32*)&ldsRef[tid], (lds_f32*)&ldsT[tid], A.spill, A.spillStride, nullptr,
                           (lds_u32*)&coopTbl[(tid >> 6) * PRT_COOP_STRIDE]};
     ArraySrc src{&A, MODE};
     Traffic tr{};
@@ -1047,6 +1047,12 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
             const double nr = (double)(q[0] ? q[0] : 1), lr = (double)(q[2] ? q[2] : 1);
             fprintf(stderr, "  mode %d lanes sitting out: node rounds %.1f on a leaf, %.1f finished, %.1f without a ray; leaf rounds %.1f on a node, %.1f finished, %.1f without a ray; %.2f hit-update turns per leaf round\n",
                     m, w[0] / nr, w[1] / nr, w[2] / nr, w[3] / lr, w[4] / lr, w[5] / lr, w[6] / lr);
+        }
+        for (int m = 0; m < 4; m++) {
+            const unsigned long long* w = h + 96 + 4 * m;
+            const double turns = (double)(h[16 + 3 * m] ? h[16 + 3 * m] : 1);
+            fprintf(stderr, "  mode %d cycles per loop turn: refill + result hand-off %.0f, entering / leaving BVHs %.0f, step phase %.0f\n", m, w[0] * 1024.0 / turns,
+                    w[1] * 1024.0 / turns, w[2] * 1024.0 / turns);
         }
         fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));

@@ -66,6 +66,21 @@ def test_rccl_standin_covers_every_symbol_the_product_binds(tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("0 "), out.stdout + out.stderr  # the stand-in's ncclGetUniqueId answered
 
 
+def test_step_loop_has_no_scratch_access():
+    """The step loop of the scatter-ray traversal (trace_queue<1, false>: node rounds + cooperative leaf rounds, ~10^9 turns per
+    C3 frame) must not touch scratch memory: a spilled value there is a memory round trip per round (round 2's lesson:
+    profiles/r02_experiments.txt 6).  tools/step_loop_isa.py compiles the kernel to gfx950 ISA with the product's flags (no GPU
+    needed), cuts the loop out by the compiler's loop annotations and lists scratch_ instructions inside it."""
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import step_loop_isa as S
+    lines = S.function_body(S.device_asm())
+    loop, body = S.step_loop(lines)
+    n, kinds, scratch = S.summary(body)
+    assert 300 < n < 2000 and kinds["ds_"] >= 20 and kinds["global_"] >= 10, (n, kinds)  # it IS the step loop
+    assert not scratch, "scratch access inside the step loop:\n" + "\n".join(scratch)
+    assert kinds["flat_"] == 0 and kinds["buffer_"] == 0, kinds  # global_ / ds_ only: no flat address-space checks
+
+
 def test_no_gpu_means_loud_failure(L):
     if L.prt_hip_device_count() > 0:
         pytest.skip("a GPU is present")
