@@ -242,7 +242,7 @@ static bool loadExrRgba(const std::vector<uint8_t>& file, int& width, int& heigh
                 if (!rdStr(cn) || pos > end) { err = "bad channel list"; return false; }
                 if (cn.empty()) break;
                 int32_t ct = 0, xs = 0, ys = 0;
-                if (!rdI(ct)) { err = "bad channel list"; return false; }
+                if (!rdI(ct) || !need(4)) { err = "bad channel list"; return false; }
                 pos += 4; // pLinear + reserved
                 if (!rdI(xs) || !rdI(ys) || pos > end) { err = "bad channel list"; return false; }
                 if (xs != 1 || ys != 1) { err = "subsampled channels are not supported"; return false; }
@@ -285,11 +285,11 @@ static bool loadExrRgba(const std::vector<uint8_t>& file, int& width, int& heigh
     for (uint32_t b = 0; b < blocks; b++) {
         uint64_t off = 0;
         memcpy(&off, &file[table + (size_t)b * 8], 8);
-        if (off + 8 > file.size()) { err = "bad block offset"; return false; }
+        if (file.size() < 8 || off > file.size() - 8) { err = "bad block offset"; return false; } // (no `off + 8`: a crafted offset near 2^64 wraps)
         int32_t y = 0, size = 0;
         memcpy(&y, &file[off], 4);
         memcpy(&size, &file[off + 4], 4);
-        if (size < 0 || off + 8 + (uint64_t)size > file.size() || y < y0 || y > y1) { err = "bad block"; return false; }
+        if (size < 0 || (uint64_t)size > file.size() - 8 - off || y < y0 || y > y1) { err = "bad block"; return false; }
         const uint32_t lines = std::min<uint32_t>(linesPerBlock, (uint32_t)(y1 - y + 1));
         const size_t expect = lineBytes * lines;
         const uint8_t* data = &file[off + 8];

@@ -825,6 +825,9 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 #ifndef PRT_COOP_WEIGHT
 #define PRT_COOP_WEIGHT 4u // ... or when leaf lanes x this many >= node lanes
 #endif
+#ifndef PRT_TRI_NT
+#define PRT_TRI_NT 0 // triangle fetches with the non-temporal hint (an experiment for trees far larger than the caches)
+#endif
 #ifndef PRT_COOP_PREPOP
 #define PRT_COOP_PREPOP 1
 #endif
@@ -882,9 +885,18 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     prt_f3 c;
     if (pair) {
         const float4* tp = sc.tris + 3 * (size_t)tri;
+#if PRT_TRI_NT
+        {
+            const prt_f4 va = __builtin_nontemporal_load((const PRT_AS1 prt_f4*)tp), vb = __builtin_nontemporal_load((const PRT_AS1 prt_f4*)(tp + 1));
+            a = make_float4(va.x, va.y, va.z, va.w);
+            b = make_float4(vb.x, vb.y, vb.z, vb.w);
+            c = __builtin_nontemporal_load((const PRT_AS1 prt_f3*)(tp + 2));
+        }
+#else
         a = gld4(tp);
         b = gld4(tp + 1);
         c = *(const PRT_AS1 prt_f3*)(tp + 2);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0); // the fetch is out before the lane exchanges, which need not wait for it
     // ---- the owner's ray constants (triangle.cpp:118-119 are per ray: prepare_shear)
@@ -982,9 +994,24 @@ __device__ __forceinline__ bool ref_is_leaf(uint32_t ref) { return (ref & PRT_RE
 // Step phase of the wave loops: a step is one internal node or one triangle.  Each round the larger of the two groups of
 // lanes steps (the other waits: SIMD lanes that cannot share an instruction stream), until PRT_IDLE_BREAK lanes have nothing
 // to step on -- their ray is finished or moves to the next BVH -- and the wave goes back to its refill point to serve them.
-template <int MODE, bool COUNT, class STK>
-__device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, bool active, const STK& st, Traffic& tr, uint32_t& overflow)
+// `queued()` (wave-uniform) tells how many rays wait in the queue the wave refills from: a wave that runs with lanes WITHOUT a
+// ray -- the queue was short when it last refilled -- looks every fourth round and goes back to its refill point as soon as
+// PRT_EMPTY_GAIN rays have arrived, instead of walking its few rays to their end at a fraction of its width.
+#ifndef PRT_EMPTY_BREAK
+#define PRT_EMPTY_BREAK 0u // lanes without a ray (plus finished ones) from which the queue is polled; 0 = never (measured: 16 / 16 costs 2 %, 8 / 8 7 %, 24 / 24 nothing: the refill turn it buys costs what the fuller rounds save)
+#endif
+#ifndef PRT_EMPTY_GAIN
+#define PRT_EMPTY_GAIN 16u
+#endif
+struct NoQueue {
+    __device__ __forceinline__ uint32_t operator()() const { return 0u; }
+};
+template <int MODE, bool COUNT, class STK, class Queued = NoQueue>
+__device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, bool active, const STK& st, Traffic& tr, uint32_t& overflow,
+                                                 const Queued& queued = Queued())
 {
+    const uint32_t empty = 64u - (uint32_t)__popcll(__ballot(active)); // (lanes take rays at the refill point only)
+    uint32_t round = 0;
     for (;;) {
         const bool onNode = active && ref_is_internal(T.ref);
         const bool onLeaf = active && ref_is_leaf(T.ref);
@@ -1024,7 +1051,12 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
         } else {
             if (onLeaf) tracer_tri<MODE, COUNT>(sc, T, st, tr);
         }
-        if ((uint32_t)__popcll(__ballot(active && T.ref == PRT_REF_NONE)) >= PRT_IDLE_BREAK) break;
+        const uint32_t done = (uint32_t)__popcll(__ballot(active && T.ref == PRT_REF_NONE));
+        if (done >= PRT_IDLE_BREAK) break;
+        if (PRT_EMPTY_BREAK && empty + done >= PRT_EMPTY_BREAK && (++round & 3u) == 0u) {
+            const uint32_t gain = empty + done < PRT_EMPTY_GAIN ? empty + done : PRT_EMPTY_GAIN;
+            if (queued() >= gain) break;
+        }
     }
 }
 

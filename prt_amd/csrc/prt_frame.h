@@ -38,6 +38,9 @@
 #ifndef PRT_TRACE_PRIO
 #define PRT_TRACE_PRIO 1
 #endif
+#ifndef PRT_SHADE_PRIO
+#define PRT_SHADE_PRIO 0 // issue priority of the wave that holds the shade role (it PRODUCES the rays the tracing waves wait for)
+#endif
 #ifndef PRT_CLAIM
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
@@ -53,7 +56,7 @@
 #ifndef PRT_WATCHDOG_SPINS
 #define PRT_WATCHDOG_SPINS (1u << 22) // idle turns (about 0.3 us each) after which a wave gives up: ~1 s
 #endif
-#define PRT_CTRL_CURSORS 256u // ctrl words: [1] watchdog flag, [2] + [8..135] its report, [256 + 32 * band] the 8 row cursors
+#define PRT_CTRL_CURSORS 256u // ctrl words: [256 + 32 * band] the 8 row cursors; behind them (PRT_WORK_WORDS..) the sticky error words: flag, watchdog reports
 #define PRT_CHUNK 64u
 #define PRT_POOL_GROUPS (PRT_POOL_CHUNKS * PRT_CHUNK)
 #define PRT_POOL_SLOTS (PRT_POOL_GROUPS * 8u) // capacity of a block's ray queue per mode: one ray per slot and mode at most
@@ -761,7 +764,11 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
             const unsigned long long pTc = __builtin_amdgcn_s_memtime();
             if (pass == 0) pTEnter += pTc - pTb;
 #endif
-            if (pass == 0) trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow);
+            if (pass == 0)
+                trace_step_phase<MODE, COUNT>(sc, T, active, st, tr, overflow, [&]() -> uint32_t {
+                    const int32_t d = (int32_t)(bcast0(lds_ld(&B->qTail[MODE])) - bcast0(lds_ld(&B->qHead[MODE])));
+                    return (heldEnd - heldNext) + (d > 0 ? (uint32_t)d : 0u);
+                });
 #ifdef PRT_PROFILE
             if (pass == 0) pTStep += __builtin_amdgcn_s_memtime() - pTc;
 #endif
@@ -835,6 +842,7 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
     const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS;
     const uint32_t lane = threadIdx.x & 63u;
     bool did = false;
+    __builtin_amdgcn_s_setprio(PRT_SHADE_PRIO);
     // ---- rows whose groups are all done take the next 64 work items
     for (uint32_t row = 0; row < A.rowsPerBlock; row++) {
         if (bcast0(lds_ld(&B->chunkLive[row])) != 0u || bcast0(lds_ld(&B->exhausted)) != 0u) continue;
@@ -914,6 +922,7 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
 #endif
         did = true;
     }
+    __builtin_amdgcn_s_setprio(0);
     return did;
 }
 
@@ -1019,10 +1028,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
             sum = wave_sum(sum);
             if (lane == 0) {
                 lds_st(&B->abort, 1u);
-                atomicExch(&A.ctrl[1], 1u);
-                const uint32_t k = atomicAdd(&A.ctrl[2], 1u);
+                uint32_t* S = A.ctrl + PRT_WORK_WORDS; // the sticky words: no render clears them (prt_sticky_error)
+                atomicOr(&S[0], 1u);
+                const uint32_t k = atomicAdd(&S[2], 1u);
                 if (k < 8u) {
-                    uint32_t* D = A.ctrl + 8 + 16 * k;
+                    uint32_t* D = S + 8 + 16 * k;
                     D[0] = blockIdx.x; D[1] = tid >> 6; D[2] = lds_ld(&B->ready); D[3] = lds_ld(&B->live); D[4] = lds_ld(&B->exhausted);
                     D[5] = lds_ld(&B->lock); D[6] = stuck; D[7] = sum;
                     for (int q = 0; q < Q_COUNT; q++) {
@@ -1060,6 +1070,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
             if (B->nHit) atomicAdd(&C[4], (unsigned long long)B->nHit);
             if (B->nTap) atomicAdd(&C[5], (unsigned long long)B->nTap);
         }
-        if (lds_ld(&B->overflow)) atomicAdd(&C[7], 1ull);
+        if (lds_ld(&B->overflow)) {
+            atomicAdd(&C[7], 1ull);
+            atomicOr(&A.ctrl[PRT_WORK_WORDS], 2u); // sticky: survives the next render's clearing of the counters
+        }
     }
 }

@@ -370,6 +370,12 @@ int prt_hip_gather(prt_hip_ctx* const* ctxs, int n, float* rgb_host, uint32_t x0
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return prt_fail(PRT_HIP_ELAUNCH, std::string("gather kernels: ") + hipGetErrorString(le));
     HIP_TRY(hipStreamSynchronize(root->stream));
+    for (int i = 0; i < n; i++) { // a launch that was cut short (watchdog, stack overflow) must not pass for an image
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        if (i) HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+        if ((rc = prt_sticky_error(ctxs[i], false))) return rc;
+    }
+    HIP_TRY(hipSetDevice(root->device));
     const size_t rowBytes = (size_t)(x1 - x0 + 1) * 3 * sizeof(float), off = ((size_t)y0 * W + x0) * 3;
     HIP_TRY(hipMemcpy2D(rgb_host + off, (size_t)W * 3 * sizeof(float), root->fb + off, (size_t)W * 3 * sizeof(float), rowBytes, y1 - y0 + 1,
                         hipMemcpyDeviceToHost));

@@ -10,6 +10,8 @@
 #include "prt_device.h"
 
 #define PRT_WORK_WORDS 512 // control words of a launch (frame kernel: prt_frame.h PRT_CTRL_CURSORS; claim cursor of the G-buffer kernel)
+#define PRT_STICKY_WORDS 160 // behind the control words and NEVER cleared by a render: [0] error flags of any earlier launch (1 watchdog, 2 stack
+                             // overflow), [2] + [8..135] the first watchdog reports; read and cleared by prt_hip_get_stats, read by download / gather
 #define PRT_STAT_SHARDS 64 // copies of the statistics counters, summed on read-back
 #ifdef PRT_PROFILE
 #define PRT_STAT_STRIDE 128 // the profile build appends its lane-utilisation counters (words 32..127)
@@ -75,4 +77,6 @@ struct prt_hip_ctx {
 };
 
 
-void prt_gather_release(prt_hip_ctx* c); // prt_gather.hip: frees the staging buffers and an owned communicator
+void prt_gather_release(prt_hip_ctx* c);
+// 0, or the error code of a launch since the last prt_hip_get_stats whose image must not be trusted (the context's stream must be idle)
+int prt_sticky_error(prt_hip_ctx* c, bool clear); // prt_gather.hip: frees the staging buffers and an owned communicator

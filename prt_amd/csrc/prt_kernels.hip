@@ -417,8 +417,8 @@ static int create_resources(prt_hip_ctx* c)
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->evOut, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(&c->work, PRT_WORK_WORDS * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->work, (PRT_WORK_WORDS + PRT_STICKY_WORDS) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->work, 0, (PRT_WORK_WORDS + PRT_STICKY_WORDS) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->counters, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->counters, 0, PRT_STAT_SHARDS * PRT_STAT_STRIDE * sizeof(unsigned long long)));
     return PRT_HIP_OK;
@@ -984,6 +984,34 @@ int prt_hip_render_gbuffer(prt_hip_ctx* c, uint32_t x0, uint32_t y0, uint32_t x1
 
 float* prt_hip_framebuffer(prt_hip_ctx* c) { return c ? c->fb : nullptr; }
 
+} // extern "C"
+
+// Errors of launches since the last prt_hip_get_stats.  Every render clears its own control words and counters, so a watchdog
+// abort or a stack overflow of an EARLIER frame of an asynchronous sequence (bench steps, render + gather loops) would be gone by
+// the time anybody looks; the frame kernel therefore also ORs them into words no render clears.
+int prt_sticky_error(prt_hip_ctx* c, bool clear)
+{
+    uint32_t S[PRT_STICKY_WORDS] = {0};
+    if (!c->work) return PRT_HIP_OK;
+    HIP_TRY(hipMemcpy(S, c->work + PRT_WORK_WORDS, sizeof(S), hipMemcpyDeviceToHost));
+    if (S[0] == 0) return PRT_HIP_OK;
+    if (clear) HIP_TRY(hipMemset(c->work + PRT_WORK_WORDS, 0, sizeof(S)));
+    if (S[0] & 1u) {
+        std::string msg = "frame kernel: scheduler watchdog fired in a launch since the last prt_hip_get_stats (a workgroup waited for work that never came; its image is incomplete);";
+        for (uint32_t k = 0; k < std::min<uint32_t>(S[2], 8u); k++) {
+            const uint32_t* D = S + 8 + 16 * k;
+            char line[256];
+            snprintf(line, sizeof(line), " [block %u wave %u: ready %u live %u exhausted %u lock %u, %u groups wait for %u rays, tails %u %u %u %u heads %u %u %u %u]",
+                     D[0], D[1], D[2], D[3], D[4], D[5], D[6], D[7], D[8], D[9], D[10], D[11], D[12], D[13], D[14], D[15]);
+            msg += line;
+        }
+        return fail(PRT_HIP_ELAUNCH, msg);
+    }
+    return fail(PRT_HIP_ESTACK, "BVH traversal needed more than 64 stack entries in a launch since the last prt_hip_get_stats (the reference asserts here, bvh.cpp:552)");
+}
+
+extern "C" {
+
 int prt_hip_download(prt_hip_ctx* c, float* rgb_host, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1)
 {
     if (!c || !rgb_host) return fail(PRT_HIP_EINVAL, "NULL argument");
@@ -996,7 +1024,7 @@ int prt_hip_download(prt_hip_ctx* c, float* rgb_host, uint32_t x0, uint32_t y0, 
     size_t off = ((size_t)y0 * W + x0) * 3;
     HIP_TRY(hipMemcpy2D(rgb_host + off, (size_t)W * 3 * sizeof(float), c->fb + off, (size_t)W * 3 * sizeof(float), rowBytes,
                         y1 - y0 + 1, hipMemcpyDeviceToHost));
-    return PRT_HIP_OK;
+    return prt_sticky_error(c, false); // the pixels are delivered, but a caller must learn that a launch behind them was cut short
 }
 
 int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
@@ -1011,21 +1039,8 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
         for (int sh = 0; sh < PRT_STAT_SHARDS; sh++)
             for (int k = 0; k < PRT_STAT_STRIDE; k++) h[k] += all[(size_t)sh * PRT_STAT_STRIDE + k];
     }
-    if (c->frameLaunched) {
-        uint32_t ctrl[8 + 16 * 8] = {0};
-        HIP_TRY(hipMemcpy(ctrl, c->work, sizeof(ctrl), hipMemcpyDeviceToHost));
-        if (ctrl[1]) {
-            std::string msg = "frame kernel: scheduler watchdog fired (a workgroup waited for work that never came);";
-            for (uint32_t k = 0; k < std::min<uint32_t>(ctrl[2], 8u); k++) {
-                const uint32_t* D = ctrl + 8 + 16 * k;
-                char line[256];
-                snprintf(line, sizeof(line), " [block %u wave %u: ready %u live %u exhausted %u lock %u, %u groups wait for %u rays, tails %u %u %u %u heads %u %u %u %u]",
-                         D[0], D[1], D[2], D[3], D[4], D[5], D[6], D[7], D[8], D[9], D[10], D[11], D[12], D[13], D[14], D[15]);
-                msg += line;
-            }
-            return fail(PRT_HIP_ELAUNCH, msg);
-        }
-    }
+    // errors of ANY launch since the last call (the last one included): see prt_sticky_error
+    const int sticky = prt_sticky_error(c, true);
 #ifdef PRT_PROFILE
     if (h[14])
         fprintf(stderr, "frame profile: waves %llu, per wave: shade %.1f%% (%.0f calls) trace %.1f%% (%.0f calls) idle/decide %.1f%% of %.2f Mcycles\n", h[14],
@@ -1081,6 +1096,7 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
     st->kernelLaunches = c->accLaunches;
     c->accMs = c->lastMs = 0.0;
     c->accLaunches = 0;
+    if (sticky) return sticky;
     if (h[7]) return fail(PRT_HIP_ESTACK, "BVH traversal needed more than 64 stack entries (the reference asserts here, bvh.cpp:552)");
     return PRT_HIP_OK;
 }

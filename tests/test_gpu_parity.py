@@ -306,7 +306,7 @@ def test_full_size_c2_properties(tracer):
         assert_bits_equal(a[y0:y0 + 16, x0:x0 + 16], ref, f"tile at {(x0, y0)}")
 
 
-# ----------------------------------------------------------------------------- stack spill, overflow, large scenes, two passes
+# ----------------------------------------------------------------------------- stack spill, overflow, large scenes
 def _geometric_soup(kmax):
     """Triangles at x = 2^k: binned SAH peels them off a few at a time, giving a tree about kmax/2 deep."""
     tris = []
@@ -332,7 +332,7 @@ def _tree_depth(nodes):
 
 
 def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer, rows):
-    """A tree deeper than the 16 stack entries kept in LDS (the rest of the 64 spill to HBM)."""
+    """A tree deeper than the 12 stack entries kept in LDS (PRT_STACK_LDS; 6 for the packet traversal; the rest of the 64 spill to HBM)."""
     idx, pos, pm, mats = _geometric_soup(56)
     scene = prt_amd.Scene()
     scene.add(prt_amd.Mesh.from_arrays(idx, pos, pm, mats.view(prt_amd.MATERIAL_DTYPE)))
@@ -340,7 +340,7 @@ def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer, rows):
     upload(tracer, scene, camera)
     upload(rows, scene, camera)
     desc = T.scene_desc_from_product(scene, camera)
-    assert 17 < _tree_depth(desc.product_arrays["meshes"][0]["nodes"]) < 60  # deeper than the 16 LDS entries
+    assert 17 < _tree_depth(desc.product_arrays["meshes"][0]["nodes"]) < 60  # deeper than the 12 LDS entries
     s = T.OracleScene(desc)
     rng = np.random.default_rng(1)
     n = 1024
@@ -365,12 +365,10 @@ def test_deep_tree_uses_the_stack_spill_and_matches_oracle(tracer, rows):
     assert_bits_equal(rgb, ref, "deep-tree radiance")
 
 
-def test_stack_overflow_is_reported_like_the_reference_assert(rows):
-    """The reference asserts when its 64-entry stack overflows (bvh.cpp:552, 627); the C-ABI returns PRT_HIP_ESTACK.
-    The binned-SAH builder does not produce such trees from sane input, so a hand-made chain BVH (every level pushes its
-    second child and descends into the first) is uploaded through the C-ABI descriptor."""
+def _chain_scene_desc(D=80):
+    """A hand-made chain BVH D levels deep (every level pushes its second child and descends into the first), as a raw C-ABI
+    scene descriptor; returns (descriptor, objects that must stay alive while it is used)."""
     import ctypes as C
-    D = 80
     n_nodes, n_prims = 2 * D + 1, D + 1
     nodes = np.zeros(n_nodes, dtype=T.NODE_DTYPE)
     nodes["lower"] = (-1e6, -1e6, -1e6)
@@ -398,6 +396,15 @@ def test_stack_overflow_is_reported_like_the_reference_assert(rows):
     md.materials = mats.ctypes.data_as(C.POINTER(prt_amd.Material))
     sd = prt_amd.SceneDesc()
     sd.meshCount, sd.meshes, sd.radius = 1, C.pointer(md), 1e4
+    return sd, (nodes, pos, idx, remap, pm, mats, md)
+
+
+def test_stack_overflow_is_reported_like_the_reference_assert(rows):
+    """The reference asserts when its 64-entry stack overflows (bvh.cpp:552, 627); the C-ABI returns PRT_HIP_ESTACK.
+    The binned-SAH builder does not produce such trees from sane input, so a hand-made chain BVH (every level pushes its
+    second child and descends into the first) is uploaded through the C-ABI descriptor."""
+    import ctypes as C
+    sd, keep = _chain_scene_desc(80)
     rows._chk(rows._L.prt_hip_upload_scene(rows._ctx, C.byref(sd)), "upload")
     org = np.tile(np.array([[0.0, 0.2, 0.2]], dtype=np.float32), (8, 1))
     d = np.tile(np.array([[1.0, 0, 0]], dtype=np.float32), (8, 1))
@@ -410,10 +417,38 @@ def test_stack_overflow_is_reported_like_the_reference_assert(rows):
             rows.stats()
 
 
-def test_large_scene_4k_two_passes_matches_oracle_tiles(tracer):
-    """C5-class at its BASELINE resolution: 3840x2160 (8.3 M pixel groups = two wavefront passes), a 1 M-triangle emissive
-    scene without directional light, depth cap 12, exposure 64; 8 spp to keep the oracle side short.  Sample tiles
-    from both passes must match the oracle bit for bit."""
+def test_an_earlier_frames_error_survives_later_renders(tracer, c1):
+    """A stack overflow in ONE frame of an asynchronous sequence must not be wiped by the frames rendered after it (every render
+    clears its own counters): the frame kernel also records it in words no render clears, and prt_hip_download /
+    prt_hip_get_stats report it -- once; the call after that is clean again."""
+    import ctypes as C
+    sd, keep = _chain_scene_desc(80)
+    t = prt_amd.PathTracer(device=0, max_depth=4, seed=1)
+    try:
+        t._chk(t._L.prt_hip_upload_scene(t._ctx, C.byref(sd)), "upload")
+        t.set_camera(prt_amd.Camera().create((0.0, 0.2, 0.2), (1.0, 0.0, 0.0), 32, 32))
+        t.render_async(0, 0, 31, 31, 8)          # scatter rays walk the chain: more than 64 stack entries
+        scene, camera, _ = c1
+        t.upload_scene(scene)
+        t.set_camera(camera)
+        t.render_async(0, 0, 63, 63, 8)          # a clean frame behind it
+        img = np.zeros((512, 512, 3), dtype=np.float32)
+        rc = t._L.prt_hip_download(t._ctx, img.ctypes.data_as(C.c_void_p), 0, 0, 63, 63)
+        assert rc == -6 and b"64 stack entries" in t._L.prt_hip_last_error()  # PRT_HIP_ESTACK, pixels delivered all the same
+        assert np.abs(img[:64, :64]).sum() > 0
+        with pytest.raises(prt_amd.PrtError, match="64 stack entries"):
+            t.stats()
+        t.stats()                                 # reported once
+        t.render_async(0, 0, 63, 63, 8)
+        t.stats()
+    finally:
+        t.close()
+
+
+def test_large_scene_4k_one_launch_matches_oracle_tiles(tracer):
+    """C5-class at its BASELINE resolution: 3840x2160 (8.3 M pixel groups, ONE launch of the frame kernel: its per-launch
+    state does not grow with the image), a 1 M-triangle emissive scene without directional light, depth cap 12, exposure 64;
+    8 spp to keep the oracle side short.  Sample tiles from the corners and the middle must match the oracle bit for bit."""
     scene, camera, _ = prt_amd.setup_atrium_standin(3840, 2160, tris=1000000, emissive_fraction=0.25, light=False)
     upload(tracer, scene, camera)
     img = tracer.render(8, max_depth=12, exposure=64.0)
@@ -636,6 +671,94 @@ def test_rccl_gather_single_rank_communicator(tracer, c1):
         t.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 6, 9])
+def test_textured_obj_scenes_through_the_asset_loaders(tracer, tmp_path, seed):
+    """SURVEY 8f.2 on the GPU: a scene that reaches the kernels THROUGH THE ASSET LOADERS -- a triangle soup written as OBJ + MTL with
+    PNG and TGA maps (random sizes 1..40 texels, not powers of two; RGB / RGBA-with-holes / grey diffuse maps, grey and RGB bump
+    maps; texture coordinates far outside [0, 1] and negative), loaded by Mesh::loadObj (mesh.cpp:151-271: usemtl, map_Kd,
+    map_bump, Ke, convertNormalToBump, isAlphaTestRequired), rendered by the frame kernel and by the oracle from the SAME loaded
+    scene: images, ray counts and every event counter (texture taps included) in the counting build, the timed build's image,
+    and the three G-buffer kinds.  (The decoders themselves are pinned by the CPU suite; what this adds is that loader output --
+    texel layout, alpha flags, per-triangle materials, bump records -- is what the device scene expects.)"""
+    from test_host_cpu import _png, _tga
+    rng = np.random.default_rng(70000 + seed)
+    td = str(tmp_path)
+
+    def tex(name, ch):
+        w, h = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        a = rng.integers(0, 256, size=(h, w, ch)).astype(np.uint8)
+        if ch == 4:
+            a[..., 3] = np.where(rng.random((h, w)) < 0.4, rng.integers(0, 120, (h, w)), 255)
+        img = a[..., 0] if ch == 1 else a
+        if name.endswith(".tga"):
+            _tga(os.path.join(td, name), img, rle=bool(seed & 1), top_down=bool(seed & 2))
+        else:
+            _png(os.path.join(td, name), img, level=(0, 1, 6, 9)[seed % 4])
+    tex("rgb.png", 3)
+    tex("rgba.tga" if seed % 3 == 0 else "rgba.png", 4)
+    tex("grey.png", 1)
+    tex("bumpg.tga" if seed % 2 else "bumpg.png", 1)
+    tex("bumpn.png", 3)
+    with open(os.path.join(td, "m.mtl"), "w") as f:
+        f.write("newmtl a\nKd 0.9 0.8 0.7\nmap_Kd rgb.png\nmap_bump %s\n" % ("bumpg.tga" if seed % 2 else "bumpg.png"))
+        f.write("newmtl b\nKd 1 1 1\nmap_Kd %s\n" % ("rgba.tga" if seed % 3 == 0 else "rgba.png"))
+        f.write("newmtl c\nKd 0.6 0.9 0.6\nmap_Kd grey.png\nmap_bump bumpn.png\n")
+        f.write("newmtl d\nKd 0.5 0.5 0.9\n")
+        f.write("newmtl e\nKd 0.2 0.2 0.2\nKe 3 2 1\n")
+    n = int(rng.integers(20, 200))
+    centre = rng.uniform(-1, 1, size=(n, 1, 3))
+    size = np.exp(rng.uniform(np.log(0.05), np.log(0.9), size=(n, 1, 1)))
+    tri = centre + size * rng.normal(size=(n, 3, 3))
+    uv = rng.uniform(-3, 4, size=(n, 3, 2)) if seed % 2 else rng.uniform(0, 1, size=(n, 3, 2))
+    with open(os.path.join(td, "s.obj"), "w") as f:
+        f.write("mtllib m.mtl\n")
+        for t in tri.reshape(-1, 3):
+            f.write("v %.9g %.9g %.9g\n" % tuple(t))
+        for t in uv.reshape(-1, 2):
+            f.write("vt %.9g %.9g\n" % tuple(t))
+        for k in range(n):
+            f.write("usemtl %s\n" % "abcde"[int(rng.integers(0, 5))])
+            i = 3 * k + 1
+            f.write(f"f {i}/{i} {i + 1}/{i + 1} {i + 2}/{i + 2}\n")
+    mesh = prt_amd.Mesh.load_obj(os.path.join(td, "s.obj"))
+    if seed % 3:
+        mesh.calculate_vertex_normals()
+    mesh.calculate_bounds()
+    scene = prt_amd.Scene()
+    scene.add(mesh)
+    arrays = scene.arrays()
+    assert len(arrays["textures"]) == 5 and int(arrays["meshes"][0]["materials"]["alphaTest"].sum()) >= 1  # the maps arrived, one with holes
+    if seed % 4 != 0:
+        d = rng.normal(size=3)
+        d[2] = abs(d[2]) + 0.3
+        d = d / np.linalg.norm(d)
+        scene.set_directional_light(tuple(d.astype(np.float32)), tuple(rng.uniform(2, 12, 3)))
+    w, h = int(rng.integers(24, 90)), int(rng.integers(16, 60))
+    eye = rng.uniform(-1, 1, 3) * 0.3 + np.array([0, 0, 3.2])
+    camera = prt_amd.Camera().create(tuple(eye), tuple(-eye + rng.normal(size=3) * 0.15), w, h)
+    depth, spp = int(rng.choice([2, 6, 14])), int(rng.choice([8, 16]))
+    upload(tracer, scene, camera)
+    osc = T.OracleScene(T.scene_desc_from_product(scene, camera, 1.0))
+    ref, ost = osc.render(spp, max_depth=depth)
+    nan = np.isnan(ref)
+
+    def same(img, what):
+        assert np.array_equal(np.isnan(img), nan), what
+        assert_bits_equal(img[~nan], ref[~nan], what)
+    same(tracer.render(spp, max_depth=depth, count_traffic=True), "counting build")
+    st = tracer.last_stats
+    assert ost["nTap"] > 0
+    for k in ("raysTraced", "occludedTraced", "nBox", "nTri", "nHit", "nTap", "nPx"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+    same(tracer.render(spp, max_depth=depth), "timed build")
+    assert tracer.last_stats["raysTraced"] == ost["raysTraced"]
+    for kind in (0, 1, 2):
+        g, gr = tracer.gbuffer(kind), osc.gbuffer(kind, (0, 0, w - 1, h - 1))
+        gn = np.isnan(gr)
+        assert np.array_equal(np.isnan(g), gn)
+        assert_bits_equal(g[~gn], gr[~gn], f"G-buffer kind {kind}")
+
+
 def test_rccl_gather_two_and_three_ranks_through_the_standin():
     """The > 1-rank branch of prt_hip_gather_rccl (prt_gather.hip: pack on the owners, the root's staging offset table, grouped
     ncclSend / ncclRecv, one de-interleave per peer) EXECUTED on this one-GPU box: PRT_RCCL_LIB points the product at
@@ -731,8 +854,7 @@ def test_full_size_c5_workload_one_rank_of_eight(tracer):
     """BASELINE config 5 AT ITS WORKLOAD, as ONE of its 8 GPUs runs it: Zero-Day-class stand-in (5 M triangles, 10 % of them
     emissive, no directional light, exposure 64; main.cpp:93-105), 3840x2160, 1024 spp, depth cap 12, rank 3 of 8 (every 8th
     16x16 tile).  Checked: exactly the rank's pixels are written, the closed form of the primary ray count, and tiles of
-    the rank equal the oracle at 1024 spp.  (A whole 4K frame is two wavefront passes: test_large_scene_4k_two_passes...;
-    one rank's share of it is one.)"""
+    the rank equal the oracle at 1024 spp.  (The whole 4K frame at 8 spp: test_large_scene_4k_one_launch_matches_oracle_tiles.)"""
     W, H, spp, depth, rank, nranks = 3840, 2160, 1024, 12, 3, 8
     scene, camera, _ = prt_amd.setup_atrium_standin(W, H, tris=5000000, seed=5, emissive_fraction=0.1, light=False)
     exposure = 64.0

@@ -352,6 +352,26 @@ def test_environment_map_from_openexr(L, tmp_path):
     with pytest.raises(prt_amd.PrtError):
         scene.set_infinite_area_light(str(tmp_path / "piz.exr"))
     assert scene.arrays()["env"] is None
+    # a crafted file must be refused, not crash the host: block offsets near 2^64 (where `off + 8` wraps), beyond the file, and a
+    # channel list cut off in the middle of an entry
+    import struct
+    _write_exr(str(tmp_path / "ok.exr"), {"R": rgb[..., 0]}, 0, 0, 0)
+    good = bytearray(open(tmp_path / "ok.exr", "rb").read())
+    # the offset table follows the header's terminating NUL: find it as the first 8-byte value that points inside the file at a block whose y is 0
+    table = next(k for k in range(8, len(good) - 16) if 0 < struct.unpack_from("<Q", good, k)[0] < len(good) - 8
+                 and struct.unpack_from("<i", good, struct.unpack_from("<Q", good, k)[0])[0] == 0 and good[k - 1] == 0)
+    for bad in (0xFFFFFFFFFFFFFFFC, 0xFFFFFFFFFFFFFFF8, len(good) - 4, len(good) + 1000):
+        raw = bytearray(good)
+        struct.pack_into("<Q", raw, table, bad)
+        open(tmp_path / "bad.exr", "wb").write(raw)
+        scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+        with pytest.raises(prt_amd.PrtError):
+            scene.set_infinite_area_light(str(tmp_path / "bad.exr"))
+    cut = good.index(b"channels\0chlist\0") + len(b"channels\0chlist\0") + 4 + 2 + 4 + 2  # inside the first entry: name "R\0", type, 2 of the 4 pLinear bytes
+    open(tmp_path / "cut.exr", "wb").write(bytes(good[:cut]))
+    scene, _, _ = prt_amd.setup_cornell_box(32, 32)
+    with pytest.raises(prt_amd.PrtError):
+        scene.set_infinite_area_light(str(tmp_path / "cut.exr"))
 
 
 def _tga(path, img, rle=False, top_down=False):
