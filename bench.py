@@ -80,7 +80,7 @@ def counter_evidence(workload, world, overridden):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("source_sha16") == prt_amd.source_sha16():
+        if d.get("workload") == workload and d.get("source_sha16") == prt_amd.loaded_source_sha16() and "rank" not in d.get("frame", ""):
             d["file"] = "profiles/" + os.path.basename(f)
             best = d
     return best
@@ -321,13 +321,20 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_rate, "hbm_frac": (traffic_rate / HBM_PEAK_GBS) if traffic_rate else None,
                          "traffic_bytes_per_launch": traffic_bytes, "traffic_source": ev["file"] if ev else None,
-                         "traffic_source_sha16": ev["source_sha16"] if ev else None, "source_sha16": prt_amd.source_sha16(),
-                         "limiter": ("latency of dependent record gathers at 8 waves per SIMD, not DRAM bytes and not instruction issue: waves wait "
-                                     f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, the gather path is busy "
-                                     f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f} of the frame, "
-                                     f"L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit {ev['derived']['l2_hit_rate']:.2f}, "
-                                     f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction; "
-                                     "+22 % vector instructions cost +4 % time; the vector ALU is 72 % busy -- the second roof, 1.39x away (DESIGN.md 4.3)") if ev
+                         "traffic_source_sha16": ev["source_sha16"] if ev else None, "source_sha16": prt_amd.loaded_source_sha16(),
+                         # what the same counter file says about the two other roofs of this kernel: the vector ALU ...
+                         "valu_busy_frac": ev["derived"].get("valu_busy_frac (SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles)") if ev else None,
+                         "lanes_per_valu": ev["derived"]["lanes_active_per_valu_instruction"] if ev else None,
+                         # ... and the rate of L2 misses, the ceiling of trees larger than the caches (64-byte gathers from beyond L2:
+                         # about 60 G per second on this chip, profiles/r02_ta_lanes.txt)
+                         "l2_misses_per_ray": ev["derived"]["l2_misses_per_ray"] if ev else None,
+                         "limiter": ("dependent record gathers (a node or a leaf per round trip) at 8 waves per SIMD, with the vector ALU as the second roof: waves wait "
+                                     f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, the vector ALU is busy "
+                                     f"{ev['derived'].get('valu_busy_frac (SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles)', float('nan')):.2f} of the frame at "
+                                     f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction, the gather path "
+                                     f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f}; L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit "
+                                     f"{ev['derived']['l2_hit_rate']:.2f}, {ev['derived']['l2_misses_per_ray']:.1f} L2 misses per ray; `frac` is algorithmic "
+                                     "(bytes of the reference's events, most of them served by LDS / L1 / L2 -- it may exceed 1), `hbm_frac` is what the fabric carries") if ev
                          else "see profiles/ (no counter summary taken with these kernel sources)",
                          "kernel": "frame_kernel: one persistent launch per frame (shade passes + four ray traversals as roles of its waves)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(B),

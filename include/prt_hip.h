@@ -144,6 +144,9 @@ int prt_hip_device_count(void);
 int prt_hip_create(int device, prt_hip_ctx** out);
 void prt_hip_destroy(prt_hip_ctx* ctx);
 const char* prt_hip_last_error(void);
+/* First 16 hex digits of the SHA-256 over the kernel sources THIS library was built from (stamped at build time): a host that
+ * quotes measurements (bench.py, the counter summaries under profiles/) compares what is loaded, not what lies in the tree. */
+const char* prt_hip_source_sha16(void);
 /* fills name (<= cap bytes) and the CU count of the context's device */
 int prt_hip_device_info(prt_hip_ctx* ctx, char* name, size_t cap, int* computeUnits);
 

@@ -103,7 +103,7 @@ MATERIAL_DTYPE = np.dtype([("diffuse", "<f4", 3), ("emissive", "<f4", 3), ("refl
 
 # every symbol include/prt_hip.h and include/prt_host.h declare
 EXPORTS = [
-    "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_device_info",
+    "prt_hip_device_count", "prt_hip_create", "prt_hip_destroy", "prt_hip_last_error", "prt_hip_source_sha16", "prt_hip_device_info",
     "prt_hip_upload_scene", "prt_hip_set_camera", "prt_hip_render", "prt_hip_render_gbuffer", "prt_hip_download", "prt_hip_framebuffer", "prt_hip_gather",
     "prt_hip_build_bvh", "prt_hip_comm_unique_id", "prt_hip_comm_init", "prt_hip_comm_adopt", "prt_hip_comm_destroy", "prt_hip_gather_rccl", "prt_hip_gather_payload_bytes",
     "prt_hip_get_stats",
@@ -130,7 +130,13 @@ def build(force=False):
 
 
 def source_sha16():
+    """Hash of the kernel sources in the tree (what a build now would be stamped with)."""
     return _build.source_sha16()
+
+
+def loaded_source_sha16():
+    """Hash of the kernel sources the LOADED library was built from (prt_hip_source_sha16): measurements are stamped with this."""
+    return lib().prt_hip_source_sha16().decode()
 
 
 def lib():
@@ -156,6 +162,7 @@ def _load(path, with_test_entry_points):
     L = C.CDLL(path)
     vp, f32p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     L.prt_hip_last_error.restype = C.c_char_p
+    L.prt_hip_source_sha16.restype = C.c_char_p
     L.prt_hip_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.prt_hip_destroy.argtypes = [vp]
     L.prt_hip_destroy.restype = None

@@ -54,7 +54,8 @@ def build_library(force=False, verbose=False, test_entry_points=False):
         return lib
     os.makedirs(LIB_DIR, exist_ok=True)
     tmp = f"{lib}.tmp.{os.getpid()}"  # concurrent builders (several ranks) never share a partial file
-    cmd = [hipcc()] + FLAGS + (["-DPRT_TEST_ENTRY_POINTS"] if test_entry_points else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    cmd = [hipcc()] + FLAGS + [f'-DPRT_SOURCE_SHA16="{source_sha16()}"'] + (["-DPRT_TEST_ENTRY_POINTS"] if test_entry_points else []) + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

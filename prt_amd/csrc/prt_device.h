@@ -34,18 +34,25 @@
 //         f32 pairs: {lo0.x hi0.x lo0.y hi0.y} {lo0.z hi0.z lo1.z hi1.z} {lo1.x hi1.x lo1.y hi1.y} {ref0 ref1 splitAxis 0}
 //         child 0 is the reference's node i+1, child 1 its m_nodes[primOrSecondNodeIndex]; refs: see PRT_REF_LEAF
 // roots:  per BVH the root's reference and box (rootRef, rootBox)
-// tris:   3 x float4 per triangle in primRemapping order {p0 primId} {p1 alphaRef} {p2 0}
-//         alphaRef = 0, or 1 + index of the alpha record
-// shade:  4 x float4 per triangle in MESH order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
+// tris:   9 floats (36 B) per triangle in primRemapping (LEAF) order, all BVHs behind one another: p0 p1 p2.  A traversal reads
+//         nothing else of a triangle unless it is a candidate: trees far larger than the caches are bound by the rate of L2 misses
+//         (profiles/r03_frame_c4_counters.json), so every byte a leaf visit does not need is kept out of its lines
+// triAlpha: per triangle, leaf order: 0, or 1 + index of its alpha record (read for candidates of leaves whose reference says
+//         that they hold an alpha-tested triangle)
+// triPrim:  per triangle, leaf order: its primId in its mesh (hits carry the LEAF-ORDER index on the device; only the row-level
+//         test entry points, which report the reference's primId, read this)
+// shade:  4 x float4 per triangle in LEAF order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
 //         (n0 = precomputed face normal when the mesh has no vertex normals)
-// bump:   3 x float4 per triangle in mesh order {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
+// bump:   3 x float4 per triangle in leaf order {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
 // mats:   5 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0} {descriptor of the diffuse map} {... of the bump map}
 //         (descriptor = {byte offset, width, height, component}, as in texDesc)
 // alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
 struct DevScene {
     const float4* wnodes;
     const float4* hotNodes; // PRT_HOT_NODES records (4 x float4 each): copies of the records that PRT_REF_HOT references name
-    const float4* tris;
+    const float* tris;
+    const uint32_t* triAlpha;
+    const uint32_t* triPrim;
     const float4* shade;
     const float4* bump;
     const float4* mats;
@@ -113,6 +120,7 @@ __device__ __forceinline__ uint32_t asu(float f) { return __float_as_uint(f); }
 #define PRT_AS1 __attribute__((address_space(1)))
 typedef float prt_f4 __attribute__((ext_vector_type(4)));
 typedef float prt_f3 __attribute__((ext_vector_type(3)));
+typedef prt_f3 prt_f3u __attribute__((aligned(4))); // a 3-vector at a 4-byte-aligned address (sizeof is still 16: index through float*)
 typedef uint32_t prt_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t prt_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 gld4(const float4* p)
@@ -408,8 +416,21 @@ __device__ __forceinline__ float tex_sample1(const DevScene& sc, uint4 d, Vec2 u
 // Child references.  A traversal never loads a node to learn what it is: the PARENT's record holds both children's
 // boxes and references (one 64-byte fetch per internal node visited, nothing fetched at a pop).
 //   internal: index of the child's own wide record (< 2^30)
-//   leaf:     PRT_REF_LEAF | firstTriangle << 4 | primCount      (primCount 1..8, firstTriangle < 2^27)
+//   leaf:     PRT_REF_LEAF | firstTriangle << 4 | hasAlpha << 3 | primCount - 1      (primCount 1..8, firstTriangle < 2^26;
+//             hasAlpha: some triangle of the leaf is alpha-tested)
 #define PRT_REF_LEAF 0x80000000u
+#define PRT_LEAF_ALPHA 8u
+__device__ __forceinline__ uint32_t leaf_count(uint32_t ref) { return (ref & 7u) + 1u; }
+__device__ __forceinline__ uint32_t leaf_first(uint32_t ref) { return (ref >> 4) & 0x7ffffffu; }
+// the three corners of leaf-order triangle `tri` (three 12-byte loads)
+__device__ __forceinline__ void load_tri(const DevScene& sc, uint32_t tri, Vec3& p0, Vec3& p1, Vec3& p2)
+{
+    const float* tp = sc.tris + 9 * (size_t)tri;
+    const prt_f3 a = *(const PRT_AS1 prt_f3u*)tp, b = *(const PRT_AS1 prt_f3u*)(tp + 3), c = *(const PRT_AS1 prt_f3u*)(tp + 6);
+    p0 = mk3(a.x, a.y, a.z);
+    p1 = mk3(b.x, b.y, b.z);
+    p2 = mk3(c.x, c.y, c.z);
+}
 // The records nearest to the roots (breadth-first, PRT_HOT_NODES of them) are visited by every ray.  References to them
 // carry PRT_REF_HOT | slot: a kernel that keeps a copy of those records in LDS (the frame kernel) reads them there with
 // ds_read_b128 instead of sending four more gathers down the texture-address path, the busiest unit of these kernels
@@ -516,14 +537,15 @@ __device__ __forceinline__ Box root_box(const DevScene& sc, uint32_t m)
 // candidate is accepted -- t in [kTriEpsilon, limit) and the alpha test, if the triangle has one, passed.  Nearest-hit
 // callers pass limit = hit.t and get hit updated; occlusion callers pass limit = maxT.
 template <bool OCCLUDE, bool PACKET, bool COUNT>
-__device__ __forceinline__ bool tri_candidate(const DevScene& sc, const float4* tp, uint32_t meshId, const DevRay& r, float limit, DevHit& hit,
+__device__ __forceinline__ bool tri_candidate(const DevScene& sc, uint32_t tri, bool leafHasAlpha, uint32_t meshId, const DevRay& r, float limit, DevHit& hit,
                                               Traffic& tr)
 {
-    float4 a = gld4(tp), b = gld4(tp + 1), c = gld4(tp + 2);
+    Vec3 p0, p1, p2;
+    load_tri(sc, tri, p0, p1, p2);
     float bi, bj, bk;
-    float t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
+    float t = tri_intersect(r, p0, p1, p2, bi, bj, bk);
     if (!(t >= 0.0001f && t < limit)) return false;
-    uint32_t alphaRef = asu(b.w);
+    const uint32_t alphaRef = leafHasAlpha ? gld(sc.triAlpha + tri) : 0u;
     if (alphaRef) {
         const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
         float4 u0 = gld4(ap), u1 = gld4(ap + 1);
@@ -536,7 +558,7 @@ __device__ __forceinline__ bool tri_candidate(const DevScene& sc, const float4* 
         hit.i = bi;
         hit.j = bj;
         hit.k = bk;
-        hit.primId = asu(a.w);
+        hit.primId = tri; // the LEAF-ORDER index: shade and bump records are stored in that order
         hit.meshId = meshId;
     }
     return true;
@@ -772,10 +794,11 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 {
     constexpr bool OCC = (MODE == PRT_MODE_OCC_PACKET || MODE == PRT_MODE_OCC_SINGLE);
     constexpr bool PACKET = (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET);
-    const uint32_t left = T.ref & 15u, tri = (T.ref >> 4) & 0x7ffffffu;
-    if (left != 0u) {
+    const uint32_t left = leaf_count(T.ref), tri = leaf_first(T.ref);
+    const bool hasAlpha = (T.ref & PRT_LEAF_ALPHA) != 0u;
+    {
         if (COUNT) tr.nTri++;
-        if (tri_candidate<OCC, PACKET, COUNT>(sc, sc.tris + 3 * (size_t)tri, T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
+        if (tri_candidate<OCC, PACKET, COUNT>(sc, tri, hasAlpha, T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
             T.occ = true;
             T.ref = PRT_REF_NONE;
             T.sp = 0;
@@ -786,7 +809,7 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
 #if PRT_TRI2
     if (left > 1u) {
         if (COUNT) tr.nTri++;
-        if (tri_candidate<OCC, PACKET, COUNT>(sc, sc.tris + 3 * (size_t)(tri + 1u), T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
+        if (tri_candidate<OCC, PACKET, COUNT>(sc, tri + 1u, hasAlpha, T.m, T.r, OCC ? T.maxT : T.hit.t, T.hit, tr) && OCC) {
             T.occ = true;
             T.ref = PRT_REF_NONE;
             T.sp = 0;
@@ -794,7 +817,7 @@ __device__ __forceinline__ void tracer_tri(const DevScene& sc, Tracer& T, const 
             return;
         }
     }
-    if (left > 2u) T.ref += 30u;
+    if (left > 2u) T.ref += 30u; // first triangle + 2 (bits 4..), triangles left - 2 (bits 0..2; no borrow: left - 1 >= 2)
     else T.ref = tracer_pop<MODE, COUNT>(T, st, tr);
 #else
     if (left > 1u) T.ref += 15u; // first triangle + 1 (bit 4), triangles left - 1
@@ -850,7 +873,7 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     constexpr bool PACKET = (MODE == PRT_MODE_PACKET || MODE == PRT_MODE_OCC_PACKET);
     const uint32_t lane = threadIdx.x & 63u;
     // ---- pairs: exclusive prefix sum of the triangle counts over the leaf lanes
-    const uint32_t n = onLeaf ? (T.ref & 15u) : 0u;
+    const uint32_t n = onLeaf ? leaf_count(T.ref) : 0u;
     const unsigned long long b0 = __ballot((n & 1u) != 0u), b1 = __ballot((n & 2u) != 0u), b2 = __ballot((n & 4u) != 0u), b3 = __ballot((n & 8u) != 0u);
     const uint32_t prefix = mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2) + 8u * mbcnt64(b3);
     const bool take = onLeaf && prefix + n <= 64u; // the prefix sum is monotone: the takers' pairs are 0 .. pairs-1
@@ -881,21 +904,17 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     const int oaddr = (int)((pair ? (word >> PRT_COOP_TRI_BITS) : lane) << 2);
     const uint32_t tri = (word + lane) & PRT_COOP_TRI_MASK;
     __builtin_amdgcn_sched_barrier(0); // (addresses first: a register of the fetch must not be reused for them while it is in flight)
-    float4 a, b;
-    prt_f3 c;
+    prt_f3 a, b, c;
     if (pair) {
-        const float4* tp = sc.tris + 3 * (size_t)tri;
+        const float* tp = sc.tris + 9 * (size_t)tri;
 #if PRT_TRI_NT
-        {
-            const prt_f4 va = __builtin_nontemporal_load((const PRT_AS1 prt_f4*)tp), vb = __builtin_nontemporal_load((const PRT_AS1 prt_f4*)(tp + 1));
-            a = make_float4(va.x, va.y, va.z, va.w);
-            b = make_float4(vb.x, vb.y, vb.z, vb.w);
-            c = __builtin_nontemporal_load((const PRT_AS1 prt_f3*)(tp + 2));
-        }
+        a = __builtin_nontemporal_load((const PRT_AS1 prt_f3u*)tp);
+        b = __builtin_nontemporal_load((const PRT_AS1 prt_f3u*)(tp + 3));
+        c = __builtin_nontemporal_load((const PRT_AS1 prt_f3u*)(tp + 6));
 #else
-        a = gld4(tp);
-        b = gld4(tp + 1);
-        c = *(const PRT_AS1 prt_f3*)(tp + 2);
+        a = *(const PRT_AS1 prt_f3u*)tp;
+        b = *(const PRT_AS1 prt_f3u*)(tp + 3);
+        c = *(const PRT_AS1 prt_f3u*)(tp + 6);
 #endif
     }
     __builtin_amdgcn_sched_barrier(0); // the fetch is out before the lane exchanges, which need not wait for it
@@ -905,7 +924,7 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     r.shearX = bperm(oaddr, T.r.shearX);
     r.shearY = bperm(oaddr, T.r.shearY);
     r.invDz = bperm(oaddr, T.r.invDz);
-    const uint32_t flags = bperm(oaddr, (T.r.swapXZ ? 1u : 0u) | (T.r.swapYZ ? 2u : 0u));
+    const uint32_t flags = bperm(oaddr, (T.r.swapXZ ? 1u : 0u) | (T.r.swapYZ ? 2u : 0u) | ((T.ref & PRT_LEAF_ALPHA) ? 4u : 0u));
     const float limit = bperm(oaddr, OCC ? T.maxT : T.hit.t);
     __builtin_amdgcn_sched_barrier(0);
     r.swapXZ = (flags & 1u) != 0u;
@@ -915,10 +934,10 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     bool cand = false;
     if (pair) {
         t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
-        primId = asu(a.w);
+        primId = tri; // the LEAF-ORDER index (tri_candidate)
         cand = t >= 0.0001f && t < limit;
-        const uint32_t alphaRef = asu(b.w);
-        if (cand && alphaRef) {
+        const uint32_t alphaRef = (cand && (flags & 4u)) ? gld(sc.triAlpha + tri) : 0u;
+        if (alphaRef) {
             const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
             const float4 u0 = gld4(ap), u1 = gld4(ap + 1);
             const Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y}; // bvh.cpp:336, 407
@@ -1154,7 +1173,7 @@ template <bool COUNT>
 __device__ __forceinline__ void get_surface(const DevScene& sc, const DevHit& h, Surface& s, Traffic& tr)
 {
     if (COUNT) tr.nHit++;
-    uint32_t gp = sc.primBase[h.meshId] + h.primId;
+    uint32_t gp = h.primId; // leaf-order index over all BVHs
     const float4* sp = sc.shade + 4 * (size_t)gp;
     float4 s0 = gld4(sp), s1 = gld4(sp + 1), s2 = gld4(sp + 2), s3 = gld4(sp + 3);
     if (sc.hasNormals[h.meshId]) {

@@ -250,7 +250,8 @@ struct ArraySrc {
     __device__ __forceinline__ void store_hit(uint32_t i, const DevHit& h) const
     {
         prt_hit o;
-        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = h.primId; o.meshId = h.meshId;
+        // the device names a hit triangle by its leaf-order index; the reference's primId is that triangle's index in its mesh
+        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = (h.t != -1.0f) ? gld(A->sc.triPrim + h.primId) : h.primId; o.meshId = h.meshId;
         A->hits[i] = o;
     }
     __device__ __forceinline__ void store_occ(uint32_t i, bool occ) const
@@ -401,6 +402,11 @@ extern "C" {
 
 const char* prt_hip_last_error(void) { return g_err.c_str(); }
 
+#ifndef PRT_SOURCE_SHA16
+#define PRT_SOURCE_SHA16 "unstamped"
+#endif
+const char* prt_hip_source_sha16(void) { return PRT_SOURCE_SHA16; }
+
 int prt_hip_device_count(void)
 {
     int n = 0;
@@ -496,7 +502,9 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     HIP_TRY(hipSetDevice(c->device));
     free_scene(c);
 
-    std::vector<float4> wnodes, tris, shade, bump, mats, alpha;
+    std::vector<float4> wnodes, shade, bump, mats, alpha;
+    std::vector<float> tris;                 // 9 floats per triangle, leaf order
+    std::vector<uint32_t> triAlpha, triPrim; // per triangle, leaf order
     std::vector<uint4> texDesc;
     std::vector<uint8_t> texels;
     DevScene sc{};
@@ -521,7 +529,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         const prt_mesh_desc& md = s->meshes[m];
         if (!md.nodes || !md.primRemapping || !md.indices || !md.positions || !md.primMaterial || !md.materials || md.nodeCount == 0)
             return fail(PRT_HIP_EINVAL, "mesh descriptor has NULL arrays");
-        const uint32_t triBase = (uint32_t)(tris.size() / 3);
+        const uint32_t triBase = (uint32_t)(tris.size() / 9);
         const uint32_t primBase = (uint32_t)(shade.size() / 4), matBase = (uint32_t)(mats.size() / PRT_MAT_STRIDE);
         sc.primBase[m] = primBase;
         sc.hasNormals[m] = md.normals ? 1u : 0u;
@@ -564,7 +572,12 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             auto refOf = [&](uint32_t i) -> uint32_t {
                 const prt_bvh_node& n = md.nodes[i];
                 if (n.primCount == 0xf) return wideIndex[i];
-                return PRT_REF_LEAF | ((triBase + n.primOrSecondNodeIndex) << 4) | n.primCount;
+                bool anyAlpha = false; // some triangle of the leaf is alpha-tested: its candidates look their alpha record up
+                for (uint32_t k = 0; k < n.primCount; k++) {
+                    const uint32_t prim = md.primRemapping[n.primOrSecondNodeIndex + k];
+                    if (prim < md.primCount && md.primMaterial[prim] < md.materialCount && md.materials[md.primMaterial[prim]].alphaTest) anyAlpha = true;
+                }
+                return PRT_REF_LEAF | ((triBase + n.primOrSecondNodeIndex) << 4) | (anyAlpha ? PRT_LEAF_ALPHA : 0u) | (n.primCount - 1u);
             };
             for (uint32_t i = 0; i < md.nodeCount; i++) {
                 const prt_bvh_node& n = md.nodes[i];
@@ -602,12 +615,15 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                 alphaRef = (uint32_t)(alpha.size() / 2);
             }
             HVec3 p0 = P(v0), p1 = P(v1), p2 = P(v2);
-            tris.push_back(make_float4(p0.x, p0.y, p0.z, ubits(prim)));
-            tris.push_back(make_float4(p1.x, p1.y, p1.z, ubits(alphaRef)));
-            tris.push_back(make_float4(p2.x, p2.y, p2.z, 0.0f));
+            const float corners[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
+            tris.insert(tris.end(), corners, corners + 9);
+            triAlpha.push_back(alphaRef);
+            triPrim.push_back(prim);
         }
-        // shading records in mesh order (Mesh::getSurfaceProperties, mesh.cpp:311-364)
-        for (uint32_t prim = 0; prim < md.primCount; prim++) {
+        // shading records (Mesh::getSurfaceProperties, mesh.cpp:311-364) in LEAF order, like the triangles: a hit names its
+        // triangle by that index
+        for (uint32_t k = 0; k < md.primCount; k++) {
+            const uint32_t prim = md.primRemapping[k];
             uint32_t v0 = md.indices[3 * prim], v1 = md.indices[3 * prim + 1], v2 = md.indices[3 * prim + 2];
             HVec3 p0 = P(v0), p1 = P(v1), p2 = P(v2);
             HVec3 n0, n1{0, 0, 0}, n2{0, 0, 0};
@@ -728,6 +744,8 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     if ((rc = upload_vec(c, wnodes, &sc.wnodes))) return rc;
     if ((rc = upload_vec(c, hot, &sc.hotNodes))) return rc;
     if ((rc = upload_vec(c, tris, &sc.tris))) return rc;
+    if ((rc = upload_vec(c, triAlpha, &sc.triAlpha))) return rc;
+    if ((rc = upload_vec(c, triPrim, &sc.triPrim))) return rc;
     if ((rc = upload_vec(c, shade, &sc.shade))) return rc;
     if ((rc = upload_vec(c, bump, &sc.bump))) return rc;
     if ((rc = upload_vec(c, mats, &sc.mats))) return rc;

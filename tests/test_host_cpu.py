@@ -81,6 +81,15 @@ def test_step_loop_has_no_scratch_access():
     assert kinds["flat_"] == 0 and kinds["buffer_"] == 0, kinds  # global_ / ds_ only: no flat address-space checks
 
 
+def test_library_carries_the_hash_of_its_sources(L):
+    """prt_amd.build() rebuilds when any kernel source or header is newer than the library (the header list is a glob of csrc/),
+    and the library is stamped with the hash of what it was built from: bench.py and the counter summaries quote that stamp."""
+    prt_amd.build()
+    assert prt_amd.loaded_source_sha16() == prt_amd.source_sha16()
+    from prt_amd import _build as B
+    assert "prt_frame.h" in B.HEADERS and "prt_device.h" in B.HEADERS
+
+
 def test_no_gpu_means_loud_failure(L):
     if L.prt_hip_device_count() > 0:
         pytest.skip("a GPU is present")

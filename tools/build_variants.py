@@ -9,7 +9,7 @@ for f in os.listdir(out):
 procs = []
 for spec in sys.argv[1:]:
     name, _, defs = spec.partition(":")
-    cmd = [B.hipcc()] + B.FLAGS + [d for d in defs.split(",") if d] + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", os.path.join(out, f"libprt_hip_{name}.so")]
+    cmd = [B.hipcc()] + B.FLAGS + [f'-DPRT_SOURCE_SHA16="{B.source_sha16()}+{name}"'] + [d for d in defs.split(",") if d] + [os.path.join(B.CSRC, s) for s in B.SOURCES] + ["-o", os.path.join(out, f"libprt_hip_{name}.so")]
     procs.append((name, subprocess.Popen(cmd)))
     if len(procs) % 4 == 0:
         for n, p in procs[-4:]:

@@ -23,5 +23,6 @@ tr = prt_amd.PathTracer(device=0, max_depth=depth, seed=12345)
 tr.upload_scene(scene); tr.set_camera(camera)
 tr.render_async(0, 0, W - 1, H - 1, spp, exposure=exposure, **kw)
 st = tr.stats()
+print("library source_sha16", prt_amd.loaded_source_sha16(), flush=True)
 print("frame kernel ms", st["kernelMs"], "rays", st["raysTraced"], "workload", name, f"{W}x{H},{spp}spp,depth{depth}" + (",rank3of8" if kw else ""), flush=True)
 tr.close()
