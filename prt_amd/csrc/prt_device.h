@@ -647,14 +647,25 @@ __device__ __forceinline__ bool tracer_next_bvh(const DevScene& sc, Tracer& T, T
         T.m++;
         if (T.m >= sc.bvhCount) return false;
         if (COUNT) tr.nBox++;
-        Box rb = root_box(sc, T.m);
+        // The lanes that come here together nearly always stand before the same BVH (new rays: the first): then the root's box and
+        // reference are uniform and arrive by scalar loads, not by two rounds of per-lane gathers from the argument block.
+        const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.m);
+        Box rb;
+        uint32_t rootRef;
+        if (__ballot(T.m != mu) == 0ull) {
+            rb = root_box(sc, mu);
+            rootRef = sc.rootRef[mu];
+        } else {
+            rb = root_box(sc, T.m);
+            rootRef = sc.rootRef[T.m];
+        }
         bool pass;
         if (MODE == PRT_MODE_PACKET) pass = box_soa(rb, T.r, T.hit.t);
         else if (MODE == PRT_MODE_SINGLE) pass = box_bool(rb, T.r, T.hit.t);
         else if (MODE == PRT_MODE_OCC_PACKET) pass = box_soa(rb, T.r, T.maxT);
         else pass = box_bool(rb, T.r, T.maxT);
         if (pass) {
-            T.ref = sc.rootRef[T.m];
+            T.ref = rootRef;
             T.sp = 0;
             return true;
         }
@@ -969,25 +980,35 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
         }
     } else {
         if (acc != 0ull) {
+            // the owners walk their accepted pairs in ascending order: only t travels per turn, the winner's barycentrics and index
+            // once at the end
+            uint32_t win = 0xffffffffu;
             for (;;) {
 #ifdef PRT_PROFILE
                 tr.pLeafUpdates++;
 #endif
                 const bool more = seg != 0u;
                 if (!__any(more)) break;
-                const int saddr = (int)((more ? prefix + (uint32_t)__builtin_ctz(seg) : lane) << 2);
-                const float t2 = bperm(saddr, t), i2 = bperm(saddr, bi), j2 = bperm(saddr, bj), k2 = bperm(saddr, bk);
-                const uint32_t p2 = bperm(saddr, primId);
+                const uint32_t src = more ? prefix + (uint32_t)__builtin_ctz(seg) : lane;
+                const float t2 = bperm((int)(src << 2), t);
                 if (more) {
                     if (t2 < T.hit.t) {
                         T.hit.t = t2;
-                        T.hit.i = i2;
-                        T.hit.j = j2;
-                        T.hit.k = k2;
-                        T.hit.primId = p2;
-                        T.hit.meshId = T.m;
+                        win = src;
                     }
                     seg &= seg - 1u;
+                }
+            }
+            if (__any(win != 0xffffffffu)) {
+                const int waddr = (int)((win != 0xffffffffu ? win : lane) << 2);
+                const float i2 = bperm(waddr, bi), j2 = bperm(waddr, bj), k2 = bperm(waddr, bk);
+                const uint32_t p2 = bperm(waddr, primId);
+                if (win != 0xffffffffu) {
+                    T.hit.i = i2;
+                    T.hit.j = j2;
+                    T.hit.k = k2;
+                    T.hit.primId = p2;
+                    T.hit.meshId = T.m;
                 }
             }
         }
@@ -1116,7 +1137,7 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
                 newBase = (uint32_t)__shfl((int)newBase, 0, 64);
             }
             if (!active && !exhausted) {
-                uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                uint32_t r = mbcnt64(need);
                 item = (r < avail) ? rangeNext + r : newBase + (r - avail);
                 if (item < n) {
                     Vec3 org, dir;

@@ -518,7 +518,7 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
         newTail[q] = 0;
         if (mask == 0ull) continue; // wave-uniform
         const uint32_t tail = bcast0(lds_ld(&B->qTail[q]));
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t rank = mbcnt64(mask);
         if (want[q]) {
             const uint32_t idx = (tail + rank) & (PRT_POOL_SLOTS - 1u);
             const uint32_t bits = owner | (q == Q_PRIMARY ? (reverseBits << 26) : 0u) | (q >= Q_OCC_PACKET ? (lightSet << 29) : 0u);
@@ -610,6 +610,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
 #ifdef PRT_PROFILE
     unsigned long long pTurns = 0, pLanes = 0, pClaims = 0, pEmptyClaims = 0, pRefills = 0, pRefillLanes = 0, pT0 = __builtin_amdgcn_s_memtime();
     unsigned long long pTRefill = 0, pTEnter = 0, pTStep = 0;
+    unsigned long long pShortTurns = 0, pShortLanes = 0, pShortOthers = 0, pShortReady = 0, pShortLock = 0;
 #endif
     for (;;) {
         // ---- 1. refill.  The wave takes PRT_CLAIM entries of the queue at a time and hands them to its lanes as they come
@@ -623,7 +624,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         if (need) {
             const uint32_t k = (uint32_t)__popcll(need);
             const uint32_t avail = heldEnd - heldNext; // wave-uniform
-            const uint32_t r = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t r = mbcnt64(need);
             uint32_t bits = 0;
             bool gotRay = false;
             if (avail != 0u) { // hand out what the wave holds: entry heldNext + r sits in lane (e & 63) of held[e >> 6]
@@ -677,6 +678,22 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
                 heldNext += k;
             }
 #ifdef PRT_PROFILE
+            {   // when lanes stay empty after the refill: where is the block's work?
+                const uint32_t short_ = (uint32_t)__popcll(__ballot(!active && !gotRay));
+                if (short_) {
+                    uint32_t others = 0;
+                    for (int q = 0; q < Q_COUNT; q++)
+                        if (q != MODE) {
+                            const int32_t d = (int32_t)(bcast0(lds_ld(&B->qTail[q])) - bcast0(lds_ld(&B->qHead[q])));
+                            others += d > 0 ? (uint32_t)d : 0u;
+                        }
+                    pShortTurns++;
+                    pShortLanes += short_;
+                    pShortOthers += others;
+                    pShortReady += bcast0(lds_ld(&B->ready));
+                    pShortLock += bcast0(lds_ld(&B->lock));
+                }
+            }
             pClaims++;
             if (!__any(gotRay)) pEmptyClaims++;
             else {
@@ -811,6 +828,11 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[34 + MODE * 8], tr.pLeafRounds);
         atomicAdd(&C[35 + MODE * 8], tr.pLeafLanes);
         atomicAdd(&C[36 + MODE * 8], tr.pTri2Lanes);
+        atomicAdd(&C[112], pShortTurns);
+        atomicAdd(&C[113], pShortLanes);
+        atomicAdd(&C[114], pShortOthers);
+        atomicAdd(&C[115], pShortReady);
+        atomicAdd(&C[116], pShortLock);
         atomicAdd(&C[96 + MODE * 4], pTRefill >> 10);
         atomicAdd(&C[97 + MODE * 4], pTEnter >> 10);
         atomicAdd(&C[98 + MODE * 4], pTStep >> 10);
@@ -895,7 +917,7 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
         if (bcast0(lds_ld(&B->chunkLive[row])) == 0u) continue;
         const uint32_t v = lds_ld_acq(&B->pending[row * PRT_CHUNK + lane]);
         const unsigned long long m = __ballot(v == 0u);
-        if (v == 0u) lds_st(&B->readyList[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))], row * PRT_CHUNK + lane);
+        if (v == 0u) lds_st(&B->readyList[n + mbcnt64(m)], row * PRT_CHUNK + lane);
         n += (uint32_t)__popcll(m);
     }
     for (uint32_t i = 0; i < n; i += 8u) {

@@ -1087,6 +1087,9 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
             fprintf(stderr, "  mode %d cycles per loop turn: refill + result hand-off %.0f, entering / leaving BVHs %.0f, step phase %.0f\n", m, w[0] * 1024.0 / turns,
                     w[1] * 1024.0 / turns, w[2] * 1024.0 / turns);
         }
+        if (h[112])
+            fprintf(stderr, "  refills that left lanes empty: %.1f M, %.1f lanes each; at that moment %.1f rays in the block's OTHER queues, %.1f groups ready for shading, shade role taken %.2f of the time\n",
+                    h[112] / 1e6, (double)h[113] / h[112], (double)h[114] / h[112], (double)h[115] / h[112], (double)h[116] / h[112]);
         fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));
     }
