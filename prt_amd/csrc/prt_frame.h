@@ -41,6 +41,12 @@
 #ifndef PRT_SHADE_PRIO
 #define PRT_SHADE_PRIO 0 // issue priority of the wave that holds the shade role (it PRODUCES the rays the tracing waves wait for)
 #endif
+#ifndef PRT_TRACE_MIN
+#define PRT_TRACE_MIN 0u // a wave at a decision point shades first when the fullest queue holds fewer rays than this and PRT_TRACE_READY groups are ready (0 = rule off)
+#endif
+#ifndef PRT_TRACE_READY
+#define PRT_TRACE_READY 8u
+#endif
 #ifndef PRT_CLAIM
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
@@ -396,6 +402,16 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
     if (needBounce) {
         // ---- one bounce (path_tracer.cpp:131-190 and the Russian roulette of :258-265)
         const bool active = slot < alive;
+#ifdef PRT_PROFILE
+        { // lanes of the pass that carry a path through its bounce (of 64)
+            const unsigned long long carrying = __ballot(slot < alive); // (this branch is per group: the ballot is of the lanes in it)
+            if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) {
+                unsigned long long* C = A.counters + (size_t)(blockIdx.x % PRT_STAT_SHARDS) * PRT_STAT_STRIDE;
+                atomicAdd(&C[118], 1ull);
+                atomicAdd(&C[119], (unsigned long long)__popcll(carrying));
+            }
+        }
+#endif
         uint32_t rtype = 2u;
         if (active) {
             const float4* mp = sc.mats + PRT_MAT_STRIDE * (size_t)material;
@@ -1010,7 +1026,8 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
         }
         const uint32_t ready = lds_ld(&B->ready), live = lds_ld(&B->live), exhausted = lds_ld(&B->exhausted);
         const bool roomForRows = exhausted == 0u && live + PRT_CHUNK <= A.rowsPerBlock * PRT_CHUNK;
-        if (ready >= PRT_SHADE_MIN || (ready > 0u && total < 64u) || (roomForRows && total < 64u) || (roomForRows && ready + live == 0u)) {
+        if (ready >= PRT_SHADE_MIN || (ready > 0u && total < 64u) || (roomForRows && total < 64u) || (roomForRows && ready + live == 0u) ||
+            (PRT_TRACE_MIN && ready >= PRT_TRACE_READY && bestLen < PRT_TRACE_MIN)) {
             uint32_t got = 0;
             if (lane == 0) got = lds_cas(&B->lock, 0u, 1u) ? 1u : 0u;
             if (bcast0(got)) {
