@@ -20,7 +20,7 @@
 #endif
 #define PRT_STACK_MAX 64     // bvh.cpp:432,579
 #ifndef PRT_BLOCK
-#define PRT_BLOCK 256
+#define PRT_BLOCK 1024 // threads per workgroup: 16 waves share the frame kernel's pool, queues and hot records (2 workgroups per CU)
 #endif
 #define PRT_MAT_STRIDE 5 // float4 per material record
 #ifndef PRT_TRI2
@@ -437,7 +437,7 @@ __device__ __forceinline__ void load_tri(const DevScene& sc, uint32_t tri, Vec3&
 // (profiles/: TA busy 76 % of the frame); other kernels read the same copy from DevScene::hotNodes.
 #define PRT_REF_HOT 0x40000000u
 #ifndef PRT_HOT_NODES
-#define PRT_HOT_NODES 64 // a power of two
+#define PRT_HOT_NODES 256 // a power of two; 16 KB of LDS per workgroup, shared by its 16 waves (64: 381-386 ms, 128: 378-381, 256: 368-371 on C3)
 #endif
 
 // Per-lane stack: entries 0..PRT_STACK_LDS-1 in LDS ([entry][thread]: conflict-free whatever the depths), deeper

@@ -11,7 +11,9 @@
 //   pending   one LDS word per group: rays of the group still in flight.  0 = ready for its next shade round.
 //   queues    four ray queues per block (primary packet rays, scatter rays, packet / single occlusion rays): rings in HBM that
 //             only this block touches, head and tail in LDS.  An entry names the owner slot; the ray is rebuilt from its state.
-//   roles     every wave alternates: SHADE (one wave at a time, LDS lock) sweeps the pending words, runs the bounce of up to 8
+//   roles     every wave alternates: SHADE (PRT_SHADERS roles per block, an LDS lock each; a role owns every PRT_SHADERS-th row of the
+//             pool and appends to the block's queues behind a reservation, published in reservation order) sweeps the pending words of
+//             its rows, runs the bounce of up to 8
 //             ready groups per pass (8 lanes per group, wave ballot / popcount compaction and prefix-counted RNG stepping as
 //             before), emits the next rays and sets pending = rays emitted;  TRACE takes the fullest queue and walks its rays
 //             with persistent lanes (a lane refills from the queue the moment its ray finishes); a finished ray's lane stores
@@ -24,13 +26,13 @@
 #pragma once
 
 #ifndef PRT_POOL_CHUNKS
-#define PRT_POOL_CHUNKS 4 // rows of 64 pixel groups a block keeps in flight
+#define PRT_POOL_CHUNKS 16 // rows of 64 pixel groups a block keeps in flight (per wave: one row, as with round 2's 4 rows for 4 waves)
 #endif
 #ifndef PRT_FRAME_WAVES
-#define PRT_FRAME_WAVES 8 // waves per SIMD the frame kernel is compiled for: 64 VGPRs, 80 SGPRs, 8 blocks of 256 per CU (18.7 KB of LDS each)
+#define PRT_FRAME_WAVES 8 // waves per SIMD the frame kernel is compiled for: 64 VGPRs, 80 SGPRs, 2 workgroups of 1024 threads per CU (78 KB of LDS each)
 #endif
 #ifndef PRT_SHADE_MIN
-#define PRT_SHADE_MIN 48u // ready groups that make a wave at a decision point take the shade role
+#define PRT_SHADE_MIN 192u // ready groups (of the pool's 1024) that make a wave at a decision point take a shade role (48: 392-402 ms, 96: 390, 192: 386 on C3)
 #endif
 #ifndef PRT_HOT_LDS
 #define PRT_HOT_LDS 1 // keep the PRT_HOT_NODES records nearest the roots in LDS (4 KB per block)
@@ -47,11 +49,15 @@
 #ifndef PRT_TRACE_READY
 #define PRT_TRACE_READY 8u
 #endif
+#ifndef PRT_SHADERS
+#define PRT_SHADERS 4 // shade roles per block (a power of two): each owns every PRT_SHADERS-th row of the pool; all append to the block's queues
+#endif
+#define PRT_SHADER_GROUPS (PRT_POOL_GROUPS / PRT_SHADERS)
 #ifndef PRT_CLAIM
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
 #ifndef PRT_DRAIN_READY
-#define PRT_DRAIN_READY 256u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade)
+#define PRT_DRAIN_READY 1024u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade): the whole pool
 #endif
 #ifndef PRT_SHADE_INLINE
 #define PRT_SHADE_INLINE __noinline__
@@ -115,8 +121,9 @@ struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
     uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
-    uint32_t lock;      // shade role
-    uint32_t ready;     // groups with pending == 0 (a hint for the role decision, not a correctness word)
+    uint32_t qRes[Q_COUNT];        // two shade roles: entries RESERVED behind the tail (published to qTail in reservation order)
+    uint32_t lock[PRT_SHADERS];    // shade role(s)
+    uint32_t ready[PRT_SHADERS];   // groups with pending == 0, per shade role (a hint for the role decision, not a correctness word)
     uint32_t live;      // groups in the pool that are not done
     uint32_t exhausted; // the global cursor has no more rows
     uint32_t abort;
@@ -155,6 +162,21 @@ __device__ __forceinline__ bool lds_cas(lds_w* p, uint32_t expect, uint32_t v)
 __device__ __forceinline__ void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void wg_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 __device__ __forceinline__ uint32_t bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ uint32_t block_ready(BlockLds B)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int h = 0; h < PRT_SHADERS; h++) r += lds_ld(&B->ready[h]);
+    return r;
+}
+__device__ __forceinline__ bool block_lock_free(BlockLds B)
+{
+    bool f = false;
+#pragma unroll
+    for (int h = 0; h < PRT_SHADERS; h++) f = f || lds_ld(&B->lock[h]) == 0u;
+    return f;
+}
 
 // Pixel of work item w (tile-major order, row-major inside a tile, main.cpp:132-138); 0xffffffff when the item lies outside
 // the rectangle or in a tile another rank owns.
@@ -527,13 +549,22 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
     // (only the wave that holds the shade lock appends, so the tails are plain LDS words for it)
     const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
     const uint32_t owner = poolLocal * 8u + slot; // slot index inside the block's pool (< PRT_POOL_SLOTS)
-    uint32_t emitted = 0, newTail[Q_COUNT];
+    uint32_t emitted = 0, newTail[Q_COUNT], qBase[Q_COUNT];
 #pragma unroll
     for (int q = 0; q < Q_COUNT; q++) {
         const unsigned long long mask = __ballot(want[q]);
         newTail[q] = 0;
+        qBase[q] = 0;
         if (mask == 0ull) continue; // wave-uniform
-        const uint32_t tail = bcast0(lds_ld(&B->qTail[q]));
+        uint32_t tail;
+        if (PRT_SHADERS > 1) { // another wave may append too: reserve the range (lane 0), publish below in reservation order
+            uint32_t t = 0;
+            if (lane == 0) t = lds_add(&B->qRes[q], (uint32_t)__popcll(mask));
+            tail = bcast0(t);
+        } else {
+            tail = bcast0(lds_ld(&B->qTail[q]));
+        }
+        qBase[q] = tail;
         const uint32_t rank = mbcnt64(mask);
         if (want[q]) {
             const uint32_t idx = (tail + rank) & (PRT_POOL_SLOTS - 1u);
@@ -585,7 +616,17 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
     if (inRange && slot == 0u) lds_st(&B->pending[poolLocal], np);
 #pragma unroll
     for (int q = 0; q < Q_COUNT; q++)
-        if (newTail[q] != 0u && lane == 0u) lds_st_rel(&B->qTail[q], newTail[q]);
+        if (newTail[q] != qBase[q] && lane == 0u) {
+            if (PRT_SHADERS > 1) {
+                // in reservation order: the tail moves over this pass's entries only when everything reserved before them is published
+                // (the other shade role publishes its queues in the same ascending order, so the two waits cannot form a cycle);
+                // bounded: a bug here must end as the watchdog's error, never as a hung GPU
+                uint32_t spins = 0;
+                while (lds_ld_acq(&B->qTail[q]) != qBase[q] && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(1);
+                if (spins >= (1u << 24)) lds_st(&B->abort, 1u);
+            }
+            lds_st_rel(&B->qTail[q], newTail[q]);
+        }
     return np;
 }
 
@@ -654,7 +695,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
             }
             if (avail < k) { // wave-uniform: the held entries are used up, take the next range
                 uint32_t newBase = 0, newGot = 0;
-                if (lane == 0 && !(lds_ld(&B->ready) >= PRT_DRAIN_READY && lds_ld(&B->lock) == 0u)) {
+                if (lane == 0 && !(block_ready(B) >= PRT_DRAIN_READY && block_lock_free(B))) {
                     for (int tries = 0; tries < 16; tries++) {
                         const uint32_t t = lds_ld_acq(&B->qTail[MODE]), h = lds_ld(&B->qHead[MODE]);
                         const int32_t queued = (int32_t)(t - h);
@@ -706,8 +747,8 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
                     pShortTurns++;
                     pShortLanes += short_;
                     pShortOthers += others;
-                    pShortReady += bcast0(lds_ld(&B->ready));
-                    pShortLock += bcast0(lds_ld(&B->lock));
+                    pShortReady += bcast0(block_ready(B));
+                    pShortLock += bcast0(block_lock_free(B) ? 0u : 1u);
                 }
             }
             pClaims++;
@@ -760,7 +801,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         if (__any(sig != PRT_NONE)) {
             wg_release();
             if (sig != PRT_NONE) {
-                if (lds_sub(&B->pending[sig], 1u) == 1u) lds_add(&B->ready, 1u);
+                if (lds_sub(&B->pending[sig], 1u) == 1u) lds_add(&B->ready[(sig / PRT_CHUNK) % PRT_SHADERS], 1u);
                 sig = PRT_NONE;
             }
         }
@@ -873,16 +914,19 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
 // ---------------------------------------------------------------------------------------------------------------- roles
 // Shade role (the caller holds the lock): give empty rows new work, then sweep the pending words and run the ready groups.
 template <bool COUNT, bool ENV>
-__device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
+__device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs, uint32_t half)
 {
     const FrameArgs& A = frame_args(kargs);
     const BlockLds B = block_lds();
     const uint32_t poolBase = blockIdx.x * PRT_POOL_GROUPS;
     const uint32_t lane = threadIdx.x & 63u;
+    half = PRT_SHADERS > 1 ? bcast0(half) : 0u; // this role's rows: half, half + PRT_SHADERS, ... (interleaved: a launch too small to fill
+                                                 // the pools gives every block its FIRST rows, and both roles must get some of them)
+    lds_w* const readyList = (lds_w*)&B->readyList[half * PRT_SHADER_GROUPS];
     bool did = false;
     __builtin_amdgcn_s_setprio(PRT_SHADE_PRIO);
     // ---- rows whose groups are all done take the next 64 work items
-    for (uint32_t row = 0; row < A.rowsPerBlock; row++) {
+    for (uint32_t row = half; row < A.rowsPerBlock; row += PRT_SHADERS) {
         if (bcast0(lds_ld(&B->chunkLive[row])) != 0u || bcast0(lds_ld(&B->exhausted)) != 0u) continue;
         // Rows come from 8 cursors, one per eighth of the work (a band of the image): a block takes rows from the band of
         // its own XCD first (blocks b and b + 8 share an XCD and its L2), so that the rays an XCD has in flight come from one
@@ -921,7 +965,7 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
         if (lane == 0) {
             lds_st(&B->chunkLive[row], n);
             lds_add(&B->live, n);
-            lds_add(&B->ready, n);
+            lds_add(&B->ready[half], n);
         }
         did = true;
         break; // one row per call: the blocks of a small launch all start at once, so its rows spread evenly over them
@@ -929,17 +973,17 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
     wg_release(); // the group headers above are read back below (other lanes of this wave) and by later shade rounds
     // ---- sweep: collect the ready groups of all rows (ballot + popcount rank into a list in LDS), then run them 8 per pass
     uint32_t n = 0;
-    for (uint32_t row = 0; row < PRT_POOL_CHUNKS; row++) {
+    for (uint32_t row = half; row < PRT_POOL_CHUNKS; row += PRT_SHADERS) {
         if (bcast0(lds_ld(&B->chunkLive[row])) == 0u) continue;
         const uint32_t v = lds_ld_acq(&B->pending[row * PRT_CHUNK + lane]);
         const unsigned long long m = __ballot(v == 0u);
-        if (v == 0u) lds_st(&B->readyList[n + mbcnt64(m)], row * PRT_CHUNK + lane);
+        if (v == 0u) lds_st(&readyList[n + mbcnt64(m)], row * PRT_CHUNK + lane);
         n += (uint32_t)__popcll(m);
     }
     for (uint32_t i = 0; i < n; i += 8u) {
         const uint32_t j = i + (lane >> 3);
         const bool has = j < n;
-        const uint32_t local = has ? lds_ld(&B->readyList[j]) : 0u;
+        const uint32_t local = has ? lds_ld(&readyList[j]) : 0u;
         const uint32_t np = shade_pass<COUNT, ENV>(kargs, has ? poolBase + local : PRT_NONE, local);
         // (shade_pass has published the groups' state, their pending words and the queue tails, in that order)
         const bool head = has && (lane & 7u) == 0u;
@@ -949,7 +993,7 @@ __device__ PRT_SHADE_INLINE bool shade_role(uint64_t kargs)
         const uint32_t nDone = (uint32_t)__popcll(__ballot(done)), nAgain = (uint32_t)__popcll(__ballot(head && np == 0u));
         if (lane == 0) {
             if (nDone) lds_sub(&B->live, nDone);
-            lds_sub(&B->ready, taken - nAgain);
+            lds_sub(&B->ready[half], taken - nAgain);
         }
 #ifdef PRT_PROFILE
         if (lane == 0) {
@@ -982,11 +1026,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
     if (tid < PRT_POOL_CHUNKS) B->chunkLive[tid] = 0;
     if (tid < Q_COUNT) {
         B->qTail[tid] = 0;
+        B->qRes[tid] = 0;
         B->qHead[tid] = 0;
     }
     if (tid == 0) {
-        B->lock = 0;
-        B->ready = 0;
+        for (int h = 0; h < PRT_SHADERS; h++) B->lock[h] = B->ready[h] = 0;
         B->live = 0;
         B->exhausted = 0;
         B->abort = 0;
@@ -1024,16 +1068,44 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
                 best = (uint32_t)q;
             }
         }
-        const uint32_t ready = lds_ld(&B->ready), live = lds_ld(&B->live), exhausted = lds_ld(&B->exhausted);
+        const uint32_t ready = block_ready(B), live = lds_ld(&B->live), exhausted = lds_ld(&B->exhausted);
         const bool roomForRows = exhausted == 0u && live + PRT_CHUNK <= A.rowsPerBlock * PRT_CHUNK;
         if (ready >= PRT_SHADE_MIN || (ready > 0u && total < 64u) || (roomForRows && total < 64u) || (roomForRows && ready + live == 0u) ||
             (PRT_TRACE_MIN && ready >= PRT_TRACE_READY && bestLen < PRT_TRACE_MIN)) {
-            uint32_t got = 0;
-            if (lane == 0) got = lds_cas(&B->lock, 0u, 1u) ? 1u : 0u;
+            // which shade role: the one with the most ready groups -- or, with nothing ready, one that has a row to give new work to;
+            // if it is taken, the next free one
+            uint32_t got = 0, half = 0;
+            if (lane == 0) {
+                if (PRT_SHADERS > 1) {
+                    uint32_t bestReady = 0, any = 0;
+                    for (uint32_t h = 0; h < PRT_SHADERS; h++) {
+                        const uint32_t r = lds_ld(&B->ready[h]);
+                        any += r;
+                        if (r > bestReady) {
+                            bestReady = r;
+                            half = h;
+                        }
+                    }
+                    if (any == 0u)
+                        for (uint32_t row = 0; row < A.rowsPerBlock; row++)
+                            if (lds_ld(&B->chunkLive[row]) == 0u) {
+                                half = row % PRT_SHADERS;
+                                break;
+                            }
+                }
+                for (uint32_t k = 0; k < PRT_SHADERS && !got; k++) {
+                    const uint32_t h = (half + k) % PRT_SHADERS;
+                    if (lds_cas(&B->lock[h], 0u, 1u)) {
+                        got = 1u;
+                        half = h;
+                    }
+                }
+            }
+            half = bcast0(half);
             if (bcast0(got)) {
                 wg_acquire();
-                did = shade_role<COUNT, ENV>(kargs);
-                if (lane == 0) lds_st_rel(&B->lock, 0u);
+                did = shade_role<COUNT, ENV>(kargs, half);
+                if (lane == 0) lds_st_rel(&B->lock[half], 0u);
                 PROF(tShade, nShade++);
             }
         }
@@ -1072,8 +1144,8 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
                 const uint32_t k = atomicAdd(&S[2], 1u);
                 if (k < 8u) {
                     uint32_t* D = S + 8 + 16 * k;
-                    D[0] = blockIdx.x; D[1] = tid >> 6; D[2] = lds_ld(&B->ready); D[3] = lds_ld(&B->live); D[4] = lds_ld(&B->exhausted);
-                    D[5] = lds_ld(&B->lock); D[6] = stuck; D[7] = sum;
+                    D[0] = blockIdx.x; D[1] = tid >> 6; D[2] = block_ready(B); D[3] = lds_ld(&B->live); D[4] = lds_ld(&B->exhausted);
+                    D[5] = block_lock_free(B) ? 0u : 1u; D[6] = stuck; D[7] = sum;
                     for (int q = 0; q < Q_COUNT; q++) {
                         D[8 + q] = lds_ld(&B->qTail[q]);
                         D[12 + q] = lds_ld(&B->qHead[q]);
