@@ -79,6 +79,11 @@ def test_step_loop_has_no_scratch_access():
     assert 300 < n < 2000 and kinds["ds_"] >= 20 and kinds["global_"] >= 10, (n, kinds)  # it IS the step loop
     assert not scratch, "scratch access inside the step loop:\n" + "\n".join(scratch)
     assert kinds["flat_"] == 0 and kinds["buffer_"] == 0, kinds  # global_ / ds_ only: no flat address-space checks
+    # the occupancy the design is built around: 64 VGPRs and at most 80 SGPRs (8 waves per SIMD), and two 1024-thread workgroups
+    # per CU (their LDS must fit twice into a CU's 160 KB)
+    res = S.kernel_resources()
+    assert res["VGPRs"] <= 64 and res["TotalSGPRs"] <= 80 and res["Occupancy"] == 8, res
+    assert 2 * res["LDS Size"] <= 160 * 1024, res
 
 
 def test_library_carries_the_hash_of_its_sources(L):

@@ -30,6 +30,22 @@ def device_asm(extra=()):
         return open(out).read()
 
 
+def kernel_resources(kernel="_Z12frame_kernelILb0ELb0EEv9FrameArgs"):
+    """{VGPRs, TotalSGPRs, ScratchSize, LDS Size, Occupancy} of the timed frame kernel, from the compiler's resource-usage remarks."""
+    flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC", "-pthread", "-ldl")]
+    cmd = [B.hipcc()] + flags + ["--cuda-device-only", "-c", os.path.join(B.CSRC, "prt_kernels.hip"), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    err = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, check=True).stderr
+    out, on = {}, False
+    for ln in err.splitlines():
+        if "Function Name:" in ln:
+            on = kernel in ln
+        elif on:
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", ln)
+            if m:
+                out[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
 def function_body(asm, name=FUNC):
     a = asm.index(f"\n{name}:")
     b = asm.index(f".size\t{name}", a)
@@ -114,6 +130,7 @@ if __name__ == "__main__":
     print("scratch_ instructions inside the loop:", len(scratch))
     for s in scratch:
         print("   ", s)
+    print("frame_kernel<false, false>:", kernel_resources())
     if "--dump" in sys.argv:
         with open(sys.argv[sys.argv.index("--dump") + 1], "w") as f:
             f.write(f"; gfx950 ISA of the step loop of trace_queue<1, false> (scatter rays), source_sha16 {B.source_sha16()}\n")
