@@ -34,16 +34,17 @@
 //         f32 pairs: {lo0.x hi0.x lo0.y hi0.y} {lo0.z hi0.z lo1.z hi1.z} {lo1.x hi1.x lo1.y hi1.y} {ref0 ref1 splitAxis 0}
 //         child 0 is the reference's node i+1, child 1 its m_nodes[primOrSecondNodeIndex]; refs: see PRT_REF_LEAF
 // roots:  per BVH the root's reference and box (rootRef, rootBox)
-// tris:   9 floats (36 B) per triangle in primRemapping (LEAF) order, all BVHs behind one another: p0 p1 p2.  A traversal reads
+// tris:   9 floats (36 B) per triangle SLOT: primRemapping (LEAF) order, all BVHs behind one another, a leaf's triangles contiguous;
+//         a leaf may start a few unused slots late so that it touches one 128-byte line less (prt_kernels.hip leaf_slots): p0 p1 p2.  A traversal reads
 //         nothing else of a triangle unless it is a candidate: trees far larger than the caches are bound by the rate of L2 misses
 //         (profiles/r03_frame_c4_counters.json), so every byte a leaf visit does not need is kept out of its lines
-// triAlpha: per triangle, leaf order: 0, or 1 + index of its alpha record (read for candidates of leaves whose reference says
+// triAlpha: per triangle slot: 0, or 1 + index of its alpha record (read for candidates of leaves whose reference says
 //         that they hold an alpha-tested triangle)
-// triPrim:  per triangle, leaf order: its primId in its mesh (hits carry the LEAF-ORDER index on the device; only the row-level
+// triPrim:  per triangle slot: its primId in its mesh (hits carry the LEAF-ORDER index on the device; only the row-level
 //         test entry points, which report the reference's primId, read this)
-// shade:  4 x float4 per triangle in LEAF order {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
+// shade:  4 x float4 per triangle slot {n0 mat} {n1 uv0.x} {n2 uv0.y} {uv1 uv2}
 //         (n0 = precomputed face normal when the mesh has no vertex normals)
-// bump:   3 x float4 per triangle in leaf order {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
+// bump:   3 x float4 per triangle slot {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
 // mats:   5 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0} {descriptor of the diffuse map} {... of the bump map}
 //         (descriptor = {byte offset, width, height, component}, as in texDesc)
 // alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}

@@ -494,6 +494,59 @@ int prt_hip_device_info(prt_hip_ctx* c, char* name, size_t cap, int* computeUnit
     return PRT_HIP_OK;
 }
 
+// Where the triangles of a mesh's leaves lie in the device arrays.  The reference keeps them in primRemapping order (leaf after leaf,
+// depth first); a leaf of n triangles is n * 36 contiguous bytes here, fetched by the n pair lanes of a cooperative leaf round at
+// once.  Beyond the caches such a fetch costs one DRAM row activation per 128-byte LINE it touches, whatever part of the line it
+// reads (profiles/r03_rec_gather.txt), and a leaf that starts at an arbitrary multiple of 36 bytes touches more lines than
+// ceil(36 n / 128) (C4's tree: 2.64 per leaf where 2.15 would do).  A leaf reference carries its first slot, so a leaf may start
+// up to PRT_LEAF_PADS unused slots later when that saves it a line (two pads: 2.22 lines per leaf for 12 % more slots).  Results
+// are unchanged: a hit's slot index is internal, and the shade, bump, alpha and primId records follow the slots.
+// slotOf[k] = slot (within the mesh) of leaf-order index k; returns the number of slots (primCount when nothing is padded).
+#ifndef PRT_LEAF_PADS
+#define PRT_LEAF_PADS 2 // (C5 share 1480 -> 1408 ms, C4 834 -> 816, C3 unchanged; 0: 2.64, 1: 2.39, 2: 2.22, 3: 2.20 lines per leaf on C4's tree)
+#endif
+static uint32_t leaf_slots(const prt_mesh_desc& md, uint32_t triBase, std::vector<uint32_t>& slotOf)
+{
+    slotOf.resize(md.primCount);
+    for (uint32_t k = 0; k < md.primCount; k++) slotOf[k] = k;
+    if (PRT_LEAF_PADS <= 0) return md.primCount;
+    std::vector<uint8_t> covered(md.primCount, 0);
+    for (uint32_t i = 0; i < md.nodeCount; i++) {
+        const prt_bvh_node& n = md.nodes[i];
+        if (n.primCount == 0xf) continue;
+        for (uint32_t t = 0; t < n.primCount; t++) {
+            if (covered[n.primOrSecondNodeIndex + t]) return md.primCount; // two leaves share a triangle: keep the reference's layout
+            covered[n.primOrSecondNodeIndex + t] = 1;
+        }
+    }
+    for (uint32_t k = 0; k < md.primCount; k++)
+        if (!covered[k]) return md.primCount;
+    auto excess = [&](uint32_t slot, uint32_t n) { // lines touched from this slot beyond the fewest a leaf of n triangles can touch
+        const uint32_t o = (uint32_t)(((uint64_t)(triBase + slot) * 36u) & 127u);
+        return (o + 36u * n + 127u) / 128u - (36u * n + 127u) / 128u;
+    };
+    // leaves in the order of their first triangle (= depth-first order for the reference's builder)
+    std::vector<std::pair<uint32_t, uint32_t>> leaves;
+    for (uint32_t i = 0; i < md.nodeCount; i++)
+        if (md.nodes[i].primCount != 0xf) leaves.push_back({md.nodes[i].primOrSecondNodeIndex, md.nodes[i].primCount});
+    std::sort(leaves.begin(), leaves.end());
+    uint32_t cursor = 0;
+    for (const auto& L : leaves) {
+        uint32_t best = 0, bestEx = excess(cursor, L.second);
+        for (uint32_t p = 1; p <= (uint32_t)PRT_LEAF_PADS && bestEx != 0u; p++) {
+            const uint32_t e = excess(cursor + p, L.second);
+            if (e < bestEx) {
+                best = p;
+                bestEx = e;
+            }
+        }
+        cursor += best;
+        for (uint32_t t = 0; t < L.second; t++) slotOf[L.first + t] = cursor + t;
+        cursor += L.second;
+    }
+    return cursor;
+}
+
 // Flattens Scene -> Bvh -> Mesh (scene.h:61-71, bvh.h:113-119, mesh.h:87-104) into the arrays of DevScene.
 int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
 {
@@ -554,6 +607,8 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             static_assert(sizeof(record) / sizeof(record[0]) == PRT_MAT_STRIDE, "material record size and PRT_MAT_STRIDE must agree");
             mats.insert(mats.end(), record, record + PRT_MAT_STRIDE);
         }
+        std::vector<uint32_t> slotOf, kOfSlot; // leaf-order index <-> slot in the device arrays (leaf_slots)
+        uint32_t slotCount = md.primCount;
         // Wide records: one per internal node, in the reference's DFS order.  wideIndex[i] = record of node i.
         {
             std::vector<uint32_t> wideIndex(md.nodeCount, 0);
@@ -569,6 +624,10 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                 }
             }
             if ((size_t)triBase + md.primCount >= (1u << PRT_COOP_TRI_BITS) || nextWide >= (1u << 30)) return fail(PRT_HIP_EINVAL, "scene too large for 32-bit child references"); // (a pair-table word holds a triangle index in 26 bits)
+            slotCount = leaf_slots(md, triBase, slotOf);
+            if ((size_t)triBase + slotCount >= (1u << PRT_COOP_TRI_BITS)) return fail(PRT_HIP_EINVAL, "scene too large for 32-bit child references");
+            kOfSlot.assign(slotCount, 0xffffffffu); // (an unused slot between two leaves: no leaf reference reaches it)
+            for (uint32_t k = 0; k < md.primCount; k++) kOfSlot[slotOf[k]] = k;
             auto refOf = [&](uint32_t i) -> uint32_t {
                 const prt_bvh_node& n = md.nodes[i];
                 if (n.primCount == 0xf) return wideIndex[i];
@@ -577,7 +636,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                     const uint32_t prim = md.primRemapping[n.primOrSecondNodeIndex + k];
                     if (prim < md.primCount && md.primMaterial[prim] < md.materialCount && md.materials[md.primMaterial[prim]].alphaTest) anyAlpha = true;
                 }
-                return PRT_REF_LEAF | ((triBase + n.primOrSecondNodeIndex) << 4) | (anyAlpha ? PRT_LEAF_ALPHA : 0u) | (n.primCount - 1u);
+                return PRT_REF_LEAF | ((triBase + slotOf[n.primOrSecondNodeIndex]) << 4) | (anyAlpha ? PRT_LEAF_ALPHA : 0u) | (n.primCount - 1u);
             };
             for (uint32_t i = 0; i < md.nodeCount; i++) {
                 const prt_bvh_node& n = md.nodes[i];
@@ -593,9 +652,15 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
             memcpy(&sc.rootBox[m][0], md.nodes[0].lower, 12);
             memcpy(&sc.rootBox[m][3], md.nodes[0].upper, 12);
         }
-        // leaf triangles in primRemapping order (TriangleVector, bvh.cpp:245-296)
-        for (uint32_t k = 0; k < md.primCount; k++) {
-            uint32_t prim = md.primRemapping[k];
+        // leaf triangles in primRemapping order (TriangleVector, bvh.cpp:245-296), leaf blocks placed by leaf_slots
+        for (uint32_t slot = 0; slot < slotCount; slot++) {
+            if (kOfSlot[slot] == 0xffffffffu) {
+                tris.insert(tris.end(), 9, 0.0f);
+                triAlpha.push_back(0u);
+                triPrim.push_back(0u);
+                continue;
+            }
+            uint32_t prim = md.primRemapping[kOfSlot[slot]];
             if (prim >= md.primCount) return fail(PRT_HIP_EINVAL, "bad primRemapping");
             uint32_t v0 = md.indices[3 * prim], v1 = md.indices[3 * prim + 1], v2 = md.indices[3 * prim + 2];
             if (v0 >= md.vertexCount || v1 >= md.vertexCount || v2 >= md.vertexCount) return fail(PRT_HIP_EINVAL, "bad vertex index");
@@ -622,8 +687,13 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         }
         // shading records (Mesh::getSurfaceProperties, mesh.cpp:311-364) in LEAF order, like the triangles: a hit names its
         // triangle by that index
-        for (uint32_t k = 0; k < md.primCount; k++) {
-            const uint32_t prim = md.primRemapping[k];
+        for (uint32_t slot = 0; slot < slotCount; slot++) {
+            if (kOfSlot[slot] == 0xffffffffu) {
+                shade.insert(shade.end(), 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                if (anyBump) bump.insert(bump.end(), 3, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                continue;
+            }
+            const uint32_t prim = md.primRemapping[kOfSlot[slot]];
             uint32_t v0 = md.indices[3 * prim], v1 = md.indices[3 * prim + 1], v2 = md.indices[3 * prim + 2];
             HVec3 p0 = P(v0), p1 = P(v1), p2 = P(v2);
             HVec3 n0, n1{0, 0, 0}, n2{0, 0, 0};

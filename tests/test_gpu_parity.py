@@ -878,6 +878,25 @@ def test_full_size_c5_workload_one_rank_of_eight(tracer):
         assert mask[y0, x0]
         ref, _ = s.render_rect((x0, y0, x0 + 15, y0 + 15), spp, max_depth=depth, stats=False)
         assert_bits_equal(img[y0:y0 + 16, x0:x0 + 16], ref, f"C5 tile at {(x0, y0)}")
+    # Full-width tile rows of the WHOLE frame against the oracle's digests (tests/golden/c5_tile_rows.npz: SHA-256 of every 16x16
+    # tile of the rows the oracle rendered at 1024 spp -- hours of CPU, done once by tools/c5_split_check.py in the build container).
+    import hashlib
+    z = np.load(os.path.join(G, "c5_tile_rows.npz"))
+    assert (int(z["width"]), int(z["height"]), int(z["spp"]), int(z["max_depth"]), float(z["exposure"])) == (W, H, spp, depth, exposure)
+    rows = [int(r) for r in z["rows"]]
+    y0, y1 = min(rows) * 16, max(rows) * 16 + 15
+    tracer.render_async(0, y0, W - 1, y1, spp, max_depth=depth, exposure=exposure)
+    band = _download(tracer, np.zeros((H, W, 3), dtype=np.float32))
+    st = tracer.stats()
+    assert st["nPx"] == (y1 - y0 + 1) * W and st["stackOverflow"] == 0
+    differing = []
+    for q, r in enumerate(rows):
+        for c in range(tiles_x):
+            tile = np.ascontiguousarray(band[r * 16:r * 16 + 16, c * 16:c * 16 + 16]).view(np.uint32).tobytes()
+            if hashlib.sha256(tile).digest() != z["sha"][q, c].tobytes():
+                differing.append((c, r))
+    assert not differing, f"{len(differing)} of {len(rows) * tiles_x} tiles of the C5 frame differ from the oracle's digests, first {differing[:4]}"
+    print(f"C5 rows {y0}..{y1}: {len(rows) * tiles_x} tiles equal the oracle's digests; {st['raysTraced'] / 1e9:.2f} G rays in {st['kernelMs']:.0f} ms")
 
 
 @pytest.mark.parametrize("spp,max_depth,seed,tile", [(24, 14, 12345, 16), (8, 1, 777, 16), (4, 14, 12345, 16), (16, 2, 1, 8), (16, 6, 99, 32),
