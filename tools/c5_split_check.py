@@ -3,7 +3,7 @@ on the same machine: the oracle needs hours of CPU for this frame (44 G rays), a
 
     c5_split_check.py gpu OUT.npz                  on the GPU box: the whole frame in one launch; per 16x16 tile the SHA-256 of its
                                                    float pixels, its float64 channel sums, and the launch's ray count
-    c5_split_check.py fixture IN.npz CPU.log OUT.npz   the digests of the tile rows the `cpu` run reported as equal in EVERY tile -- the
+    c5_split_check.py fixture IN.npz OUT.npz CPU.log...  the digests of the tile rows the `cpu` runs reported as equal in EVERY tile -- the
                                                    oracle's output for those rows (equal SHA-256 = equal bytes) -- as the
                                                    fixture of the GPU suite (tests/golden/c5_tile_rows.npz)
     c5_split_check.py cpu IN.npz MINUTES [ROW0]    anywhere: the oracle (all threads given by PRT_ORACLE_THREADS, default all cores)
@@ -47,9 +47,11 @@ def main():
         import re
         z = np.load(sys.argv[2])
         tx = (W + TILE - 1) // TILE
-        rows = sorted(int(m.group(1)) for m in re.finditer(r"^tile row (\d+) .*: (\d+) of (\d+) tiles equal", open(sys.argv[3]).read(), re.M)
-                      if m.group(2) == m.group(3) == str(tx))
-        np.savez_compressed(sys.argv[4], rows=np.array(rows, dtype=np.int32), sha=z["sha"][rows], width=W, height=H, spp=SPP, max_depth=DEPTH,
+        text = "\n".join(open(f).read() for f in sys.argv[4:])
+        assert "DIFFERENT" not in re.sub(r"\b0 DIFFERENT", "", text), "a run reported differing tiles"
+        rows = sorted({int(m.group(1)) for m in re.finditer(r"^tile row (\d+) .*: (\d+) of (\d+) tiles equal", text, re.M)
+                       if m.group(2) == m.group(3) == str(tx)})
+        np.savez_compressed(sys.argv[3], rows=np.array(rows, dtype=np.int32), sha=z["sha"][rows], width=W, height=H, spp=SPP, max_depth=DEPTH,
                             exposure=np.float32(EXPOSURE), seed=12345)
         print(f"{len(rows)} tile rows ({len(rows) * tx} tiles, {100.0 * len(rows) * TILE / H:.1f} % of the frame): rows {rows}")
         return 0
