@@ -325,8 +325,9 @@ def main():
                          # what the same counter file says about the two other roofs of this kernel: the vector ALU ...
                          "valu_busy_frac": ev["derived"].get("valu_busy_frac (SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles)") if ev else None,
                          "lanes_per_valu": ev["derived"]["lanes_active_per_valu_instruction"] if ev else None,
-                         # ... and the rate of L2 misses, the ceiling of trees larger than the caches (64-byte gathers from beyond L2:
-                         # about 60 G per second on this chip, profiles/r02_ta_lanes.txt)
+                         # ... and the rate of L2 misses, the ceiling of trees larger than the caches (dependent 64-byte gathers from beyond
+                         # the caches: 53-56 G per second on this chip, a whole 128-byte line for the price of one sector:
+                         # profiles/r03_rec_gather.txt; the large scenes run at 50-52 G misses per second)
                          "l2_misses_per_ray": ev["derived"]["l2_misses_per_ray"] if ev else None,
                          "limiter": ("dependent record gathers (a node or a leaf per round trip) at 8 waves per SIMD, with the vector ALU as the second roof: waves wait "
                                      f"{ev['derived']['wave_time_waiting_frac (SQ_WAIT_ANY / SQ_WAVE_CYCLES)']:.2f} of their time, the vector ALU is busy "

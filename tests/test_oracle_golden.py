@@ -249,3 +249,25 @@ def test_scene_digests_match_reference(name, setup, kw, w, h):
     assert st["raysTraced"] == int(z[f"{name}_rays"][0]) and st["occludedTraced"] == int(z[f"{name}_rays"][1])
     digest = np.frombuffer(hashlib.sha256(np.ascontiguousarray(rgb, dtype="<f4").tobytes()).digest(), dtype=np.uint8)
     assert np.array_equal(digest, z[f"{name}_sha256"])
+
+
+def test_c5_tile_row_fixture_is_oracle_output_for_one_tile():
+    """tests/golden/c5_tile_rows.npz (tools/c5_split_check.py): SHA-256 digests of 16x16 tiles of BASELINE config 5 (3840x2160,
+    1024 spp, depth 12, exposure 64) as the ORACLE rendered them -- hours of CPU, done once.  Here: the fixture is well formed, and
+    one of its tiles, rendered again by the oracle, gives the stored digest (a tile of 1024 spp on a 5 M triangle scene is about a
+    minute of one core's work; the scene comes from the product's generator, as it does for the GPU test that uses the fixture)."""
+    import hashlib
+    import prt_amd
+    z = np.load(os.path.join(G, "c5_tile_rows.npz"))
+    W, H, spp, depth, exposure = int(z["width"]), int(z["height"]), int(z["spp"]), int(z["max_depth"]), float(z["exposure"])
+    assert (W, H, spp, depth, exposure, int(z["seed"])) == (3840, 2160, 1024, 12, 64.0, 12345)
+    rows = [int(r) for r in z["rows"]]
+    assert len(set(rows)) == len(rows) and all(0 <= r < H // 16 for r in rows) and z["sha"].shape == (len(rows), W // 16, 32)
+    if os.environ.get("PRT_SKIP_SLOW_ORACLE"):
+        return
+    scene, camera, _ = prt_amd.setup_atrium_standin(W, H, tris=5000000, seed=5, emissive_fraction=0.1, light=False)
+    s = T.OracleScene(T.scene_desc_from_product(scene, camera, exposure))
+    q, c = len(rows) // 2, 7  # a tile near the left edge (cheap pixels) of the middle fixture row
+    x0, y0 = c * 16, rows[q] * 16
+    tile, _ = s.render_rect((x0, y0, x0 + 15, y0 + 15), spp, max_depth=depth, stats=False)
+    assert hashlib.sha256(np.ascontiguousarray(tile, dtype=np.float32).view(np.uint32).tobytes()).digest() == z["sha"][q, c].tobytes()
