@@ -283,6 +283,27 @@ def test_error_behaviour(tracer, rows, c1):
 
 
 # ----------------------------------------------------------------------------- BASELINE full size: properties
+
+def assert_frame_equals_oracle_digests(img, stats, name, spp, depth, exposure):
+    """The WHOLE frame against the oracle's frame, tile by tile: tests/golden/<name> holds the SHA-256 of every 16x16 tile of the frame
+    as the oracle rendered it at the configuration's own sample count (tools/whole_frame_digests.py: minutes to an hour of all
+    cores, done once) and the oracle's ray counts."""
+    import hashlib
+    z = np.load(os.path.join(G, name))
+    H, W, _ = img.shape
+    assert (int(z["width"]), int(z["height"]), int(z["spp"]), int(z["max_depth"]), float(z["exposure"]), int(z["seed"])) == (W, H, spp, depth, float(exposure), 12345)
+    ty, tx = (H + 15) // 16, (W + 15) // 16
+    assert z["sha"].shape == (ty, tx, 32)
+    differing = []
+    for r in range(ty):
+        for c in range(tx):
+            tile = np.ascontiguousarray(img[r * 16:r * 16 + 16, c * 16:c * 16 + 16]).view(np.uint32).tobytes()
+            if hashlib.sha256(tile).digest() != z["sha"][r, c].tobytes():
+                differing.append((c, r))
+    assert not differing, f"{len(differing)} of {ty * tx} tiles differ from the oracle's frame ({name}), first {differing[:4]}"
+    assert (stats["raysTraced"], stats["occludedTraced"]) == (int(z["rays"]), int(z["occluded"]))
+
+
 def test_full_size_c2_properties(tracer):
     """Config C2 at BASELINE size (1024x1024, 64 spp): too slow for the CPU oracle in a unit test, so check
     size-independent properties -- determinism, the closed form of the primary ray count, invariance to how the
@@ -296,6 +317,7 @@ def test_full_size_c2_properties(tracer):
     assert a.tobytes() == b.tobytes() and sa["raysTraced"] == sb["raysTraced"]
     assert sa["nPx"] == 1024 * 1024 and sa["raysTraced"] >= 64 * 1024 * 1024
     assert np.isfinite(a).all() and (a >= 0).all()
+    assert_frame_equals_oracle_digests(a, sa, "frame_digests_c2.npz", 64, 14, exposure)  # the whole frame == the oracle's frame
     top = tracer.trace_block(0, 0, 1023, 511, 64)
     bot = tracer.trace_block(0, 512, 1023, 1023, 64)
     assert np.concatenate([top, bot], 0).tobytes() == a.tobytes()
@@ -790,6 +812,7 @@ def test_full_size_c3_properties(tracer):
     assert a.tobytes() == b.tobytes() and tracer.last_stats["raysTraced"] == sa["raysTraced"]
     assert sa["nPx"] == W * H and sa["raysTraced"] >= spp * W * H and sa["occludedTraced"] > 0
     assert np.isfinite(a).all() and (a >= 0).all()
+    assert_frame_equals_oracle_digests(a, sa, "frame_digests_c3.npz", spp, depth, exposure)  # the whole frame == the oracle's frame
     # ranks 0..2 of 3 into one image: every tile has exactly one owner
     union = np.zeros_like(a)
     rays = 0
@@ -830,6 +853,8 @@ def test_full_size_c4_workload(tracer):
     assert sa["nPx"] == W * H and sa["stackOverflow"] == 0 and sa["raysTraced"] >= spp * W * H and sa["occludedTraced"] > 0
     assert np.isfinite(a).all() and (a >= 0).all()
     print(f"C4 frame: {sa['raysTraced'] / 1e9:.2f} G rays in {sa['kernelMs']:.0f} ms = {sa['raysTraced'] / sa['kernelMs'] / 1e3:.0f} Mray/s")
+    if os.path.exists(os.path.join(G, "frame_digests_c4.npz")):  # (TEMPORARY guard while the oracle's C4 frame is being rendered)
+        assert_frame_equals_oracle_digests(a, sa, "frame_digests_c4.npz", spp, depth, exposure)  # the whole frame == the oracle's frame
     b = tracer.render(spp, max_depth=depth, exposure=exposure)
     assert a.tobytes() == b.tobytes() and tracer.last_stats["raysTraced"] == sa["raysTraced"]
     union = np.zeros_like(a)

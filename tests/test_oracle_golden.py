@@ -271,3 +271,28 @@ def test_c5_tile_row_fixture_is_oracle_output_for_one_tile():
     x0, y0 = c * 16, rows[q] * 16
     tile, _ = s.render_rect((x0, y0, x0 + 15, y0 + 15), spp, max_depth=depth, stats=False)
     assert hashlib.sha256(np.ascontiguousarray(tile, dtype=np.float32).view(np.uint32).tobytes()).digest() == z["sha"][q, c].tobytes()
+
+
+@pytest.mark.parametrize("name,setup,kw,tile", [
+    ("c2", "setup_bunny_standin", {}, (31, 40)),
+    ("c3", "setup_atrium_standin", dict(tris=262000, seed=1), (60, 33)),
+    ("c4", "setup_atrium_standin", dict(tris=2500000, seed=4), (11, 50)),
+])
+def test_whole_frame_digest_fixtures_are_oracle_output(name, setup, kw, tile):
+    """tests/golden/frame_digests_c{2,3,4}.npz (tools/whole_frame_digests.py): SHA-256 of every 16x16 tile of a BASELINE
+    configuration's whole frame as the ORACLE rendered it, which the GPU suite compares its whole frames with.  Here: each fixture
+    is well formed and one of its tiles, rendered again by the oracle, gives the stored digest."""
+    import hashlib
+    import prt_amd
+    if name == "c4" and not os.path.exists(os.path.join(G, "frame_digests_c4.npz")):
+        pytest.skip("TEMPORARY: the oracle's C4 frame is being rendered")
+    z = np.load(os.path.join(G, f"frame_digests_{name}.npz"))
+    W, H, spp, depth, exposure = int(z["width"]), int(z["height"]), int(z["spp"]), int(z["max_depth"]), float(z["exposure"])
+    assert z["sha"].shape == ((H + 15) // 16, (W + 15) // 16, 32) and int(z["seed"]) == 12345 and int(z["rays"]) >= spp * W * H
+    scene, camera, exp = getattr(prt_amd, setup)(W, H, **kw)
+    assert float(np.float32(exp)) == exposure
+    s = T.OracleScene(T.scene_desc_from_product(scene, camera, exp))
+    c, r = tile
+    x0, y0 = c * 16, r * 16
+    crop, _ = s.render_rect((x0, y0, min(W, x0 + 16) - 1, min(H, y0 + 16) - 1), spp, max_depth=depth, stats=False)
+    assert hashlib.sha256(np.ascontiguousarray(crop, dtype=np.float32).view(np.uint32).tobytes()).digest() == z["sha"][r, c].tobytes()
