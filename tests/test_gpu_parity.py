@@ -853,8 +853,7 @@ def test_full_size_c4_workload(tracer):
     assert sa["nPx"] == W * H and sa["stackOverflow"] == 0 and sa["raysTraced"] >= spp * W * H and sa["occludedTraced"] > 0
     assert np.isfinite(a).all() and (a >= 0).all()
     print(f"C4 frame: {sa['raysTraced'] / 1e9:.2f} G rays in {sa['kernelMs']:.0f} ms = {sa['raysTraced'] / sa['kernelMs'] / 1e3:.0f} Mray/s")
-    if os.path.exists(os.path.join(G, "frame_digests_c4.npz")):  # (TEMPORARY guard while the oracle's C4 frame is being rendered)
-        assert_frame_equals_oracle_digests(a, sa, "frame_digests_c4.npz", spp, depth, exposure)  # the whole frame == the oracle's frame
+    assert_frame_equals_oracle_digests(a, sa, "frame_digests_c4.npz", spp, depth, exposure)  # the whole frame == the oracle's frame
     b = tracer.render(spp, max_depth=depth, exposure=exposure)
     assert a.tobytes() == b.tobytes() and tracer.last_stats["raysTraced"] == sa["raysTraced"]
     union = np.zeros_like(a)

@@ -284,8 +284,6 @@ def test_whole_frame_digest_fixtures_are_oracle_output(name, setup, kw, tile):
     is well formed and one of its tiles, rendered again by the oracle, gives the stored digest."""
     import hashlib
     import prt_amd
-    if name == "c4" and not os.path.exists(os.path.join(G, "frame_digests_c4.npz")):
-        pytest.skip("TEMPORARY: the oracle's C4 frame is being rendered")
     z = np.load(os.path.join(G, f"frame_digests_{name}.npz"))
     W, H, spp, depth, exposure = int(z["width"]), int(z["height"]), int(z["spp"]), int(z["max_depth"]), float(z["exposure"])
     assert z["sha"].shape == ((H + 15) // 16, (W + 15) // 16, 32) and int(z["seed"]) == 12345 and int(z["rays"]) >= spp * W * H
