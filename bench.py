@@ -171,6 +171,21 @@ def cpu_baseline(scene, camera, exposure, spp, max_depth, seed, budget_seconds, 
                             f" ({px(rect)} pixels)")
 
 
+def spawn_ranks(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child and wait for it: one
+    process per GPU, rendezvous on 127.0.0.1 at a port that is free now.  Returns the child's exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +201,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=120.0, help="budget of the CPU leg: the whole frame when a probe says it fits, else a window")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  A CHILD process (never an exec: this pool
+        # forbids replacing a process, and nothing here has touched the GPU yet anyway); its stdout -- rank 0's one JSON line --
+        # passes through and its exit code is ours.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     # stdout carries ONE JSON line: whatever libraries print there while the run lasts (RCCL's version banner, for one) goes to
     # stderr, and the line is written to the real stdout at the end
     real_stdout = os.fdopen(os.dup(1), "w")
@@ -200,10 +221,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            # `python bench.py --gpus N` without a launcher: N independent ranks need torchrun
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+        args.gpus = world  # (a launcher's world size wins over the flag)
+    if os.environ.get("PRT_BENCH_LAUNCH_PROBE"):
+        # the launcher test (tests/test_multi_rank_cpu.py): say what this rank saw and stop before a device is needed
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus,
+                          "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), file=real_stdout, flush=True)
+        return
+    # (device_count() does not initialise the GPU on this image; is_available() does)
+    have = torch.cuda.device_count()
+    if have < world or local_rank >= have:
+        raise SystemExit(f"bench.py: need {world} devices for --gpus {world}, this node shows {have}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -84,3 +84,23 @@ def test_pack_and_unpack_are_inverse_and_tile_major():
             assert p.shape[0] == len(prt_amd.owned_tile_ids(w, h, r, n))
             prt_amd.unpack_tiles(out, p, r, n)
         assert out.tobytes() == img.tobytes()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts torch.distributed.run as a CHILD:
+    the two ranks see RANK / WORLD_SIZE / a 127.0.0.1 rendezvous (probe mode stops them before a device is needed), and without
+    the probe the run fails with "need 2 devices" -- here, where there are none -- not with a usage message."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    probe = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, PRT_BENCH_LAUNCH_PROBE="1"),
+                           capture_output=True, text=True, timeout=300)
+    assert probe.returncode == 0, probe.stderr[-2000:]
+    seen = sorted((json.loads(line) for line in probe.stdout.splitlines() if line.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in seen] == [0, 1] and all(d["world"] == 2 and d["gpus"] == 2 for d in seen)
+    assert all(d["master"].startswith("127.0.0.1:") for d in seen) and seen[0]["master"] == seen[1]["master"]
+    if torch.cuda.device_count() < 2:
+        real = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+        assert real.returncode != 0 and real.stdout.strip() == ""
+        assert "need 2 devices" in real.stderr and "launch N > 1 with" not in real.stderr
