@@ -65,6 +65,36 @@ def algorithmic_split(st):
     return out
 
 
+# Measured ceiling of dependent 64-byte record gathers from beyond the L2 at this kernel's occupancy (8 waves per SIMD), by the size of
+# the table gathered from: tools/rec_gather.hip, profiles/r03_rec_gather.txt (G records per second of the whole chip)
+GATHER_ROOF = ((64e6, 81.1, "a 16 MB table: inside the Infinity Cache"), (512e6, 55.9, "a 256 MB table"), (float("inf"), 52.9, "a 2 GB table: DRAM row activations"))
+
+
+def binding_roof(ev, kernel_ms, tree_bytes):
+    """The roofs that can bind the frame kernel, each as a MEASURED fraction <= 1 from the committed counter summary `ev`,
+    and the one that binds = the largest.  The contract's algorithmic figure (bytes of the reference's events / time / 8 TB/s) is not
+    among them: most of those bytes are served by LDS, L1 and L2, and it exceeds 1 on the headline configuration."""
+    d, sec = ev["derived"], kernel_ms * 1e-3
+    raw = ev["counters_raw"]
+    # everything below is per second of THIS run's kernel time: the counters are event counts of one frame (deterministic work)
+    clock = raw["GRBM_GUI_ACTIVE"] / 8 / (ev.get("kernel_ms_under_profiler_median", kernel_ms) * 1e-3)
+    valu_busy = raw["SQ_INSTS_VALU"] * 3.07 / 1024.0 / (clock * sec)
+    lanes = d["lanes_active_per_valu_instruction"]
+    miss_rate = raw["TCC_MISS_sum"] / sec / 1e9
+    roof_g, roof_note = next((g, n) for lim, g, n in GATHER_ROOF if tree_bytes <= lim)
+    roofs = {
+        "valu_useful": {"frac": min(1.0, valu_busy) * lanes / 64.0,
+                        "formula": "SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles (vector ALU busy) x SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64 (lanes that do work)",
+                        "valu_busy_frac": valu_busy, "lanes_per_valu": lanes},
+        "l2_miss_rate": {"frac": miss_rate / roof_g, "formula": f"TCC_MISS_sum / kernel time / {roof_g} G per second (dependent 64-byte gathers from {roof_note}; profiles/r03_rec_gather.txt)",
+                         "achieved_G_per_s": miss_rate, "roof_G_per_s": roof_g, "l2_misses_per_ray": d["l2_misses_per_ray"]},
+        "hbm_bytes": {"frac": ev["traffic_bytes_per_frame"] / sec / 1e9 / HBM_PEAK_GBS, "formula": "(FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s",
+                      "achieved_GBps": ev["traffic_bytes_per_frame"] / sec / 1e9},
+    }
+    name = max(roofs, key=lambda k: roofs[k]["frac"])
+    return name, roofs
+
+
 def counter_evidence(workload, world, overridden):
     """The committed counter summary of this workload (profiles/*_counters.json: separate rocprofv3 --pmc passes, one counter
     block each, summarised by tools/pmc_evidence.py), or None.  It is only used when it was taken with the kernel sources this
@@ -333,6 +363,11 @@ def main():
         traffic_rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9 if ev else None
         value = rays_per_step * args.steps / dt / 1e6
         name, cus = tracer.device_info()
+        # tree bytes of the workload (64-byte records of the internal nodes + 36-byte triangle slots, ~1.12 slots per triangle with the
+        # padded leaf blocks): which of the measured gather ceilings applies
+        tris = int(kw.get("tris", 0)) or 16000
+        tree_bytes = tris * (36 * 1.12 + 64 * 0.35)
+        bind, roofs = binding_roof(ev, kernel_ms, tree_bytes) if ev else (None, None)
         out = {
             "metric": "Mray/s (primary+secondary) at 1080p/64spp; 1/2/4/8-GPU scaling",
             "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -345,7 +380,12 @@ def main():
             # `achieved` / `frac` are the contract's ALGORITHMIC figure (layout-independent bytes of the events the
             # reference's algorithm performs, most of them served by L1/L2) -- not a claim that DRAM is busy.  What DRAM and the
             # memory pipeline really do is beside it: `traffic` / `hbm_frac` (fabric-side counters) and `limiter` (from the same file).
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # `frac` = the roof that BINDS, a measured fraction <= 1 named by `frac_of` (the largest of `roofs`: useful share of the vector
+            # ALU, L2-miss rate against the measured gather ceiling, fabric bytes against 8 TB/s); `achieved` / `algorithmic_frac` keep
+            # SURVEY 8d's contract figure, which is not a fraction of anything (it exceeds 1 on this configuration)
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": roofs[bind]["frac"] if ev else None, "frac_of": (bind + ": " + roofs[bind]["formula"]) if ev else None, "roofs": roofs,
+                         "algorithmic_frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_rate, "hbm_frac": (traffic_rate / HBM_PEAK_GBS) if traffic_rate else None,
                          "traffic_bytes_per_launch": traffic_bytes, "traffic_source": ev["file"] if ev else None,
                          "traffic_source_sha16": ev["source_sha16"] if ev else None, "source_sha16": prt_amd.loaded_source_sha16(),
@@ -361,8 +401,8 @@ def main():
                                      f"{ev['derived'].get('valu_busy_frac (SQ_INSTS_VALU x 3.07 cycles / 1024 SIMDs / frame cycles)', float('nan')):.2f} of the frame at "
                                      f"{ev['derived']['lanes_active_per_valu_instruction']:.1f} of 64 lanes per vector instruction, the gather path "
                                      f"{ev['derived']['ta_busy_frac (TA_BUSY_avr / cycles of the frame)']:.2f}; L1 hit {ev['derived']['l1_hit_rate']:.2f}, L2 hit "
-                                     f"{ev['derived']['l2_hit_rate']:.2f}, {ev['derived']['l2_misses_per_ray']:.1f} L2 misses per ray; `frac` is algorithmic "
-                                     "(bytes of the reference's events, most of them served by LDS / L1 / L2 -- it may exceed 1), `hbm_frac` is what the fabric carries") if ev
+                                     f"{ev['derived']['l2_hit_rate']:.2f}, {ev['derived']['l2_misses_per_ray']:.1f} L2 misses per ray; `algorithmic_frac` counts the bytes of the "
+                                     "reference's events, most of them served by LDS / L1 / L2 -- it may exceed 1; `frac` is the binding roof of `roofs`") if ev
                          else "see profiles/ (no counter summary taken with these kernel sources)",
                          "kernel": "frame_kernel: one persistent launch per frame (shade passes + four ray traversals as roles of its waves)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(B),

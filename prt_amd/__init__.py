@@ -441,9 +441,22 @@ class PathTracer:
         self.render_async(x0, y0, x1, y1, samples, **kw)
         W, H = self._camera.width, self._camera.height
         img = np.zeros((H, W, 3), dtype=np.float32)
-        self._chk(self._L.prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        self._download(img, x0, y0, x1, y1)
         self.last_stats = self.stats()  # raises on stack overflow
         return img[y0:y1 + 1, x0:x1 + 1].copy()
+
+    def _download(self, img, x0, y0, x1, y1):
+        """prt_hip_download reports an earlier launch's error (watchdog, stack overflow) WITHOUT clearing it -- the C-ABI's rule:
+        only prt_hip_get_stats consumes it.  The calls of this class that download also own the frame, so they consume it
+        here: the error is raised once and the next render on this tracer starts clean."""
+        try:
+            self._chk(self._L.prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        except PrtError:
+            try:
+                self.stats()
+            except PrtError:
+                pass
+            raise
 
     def gbuffer(self, kind, x0=0, y0=0, x1=None, y1=None, exposure=1.0):
         """GbufferVisualizer::TraceBlock (gbuffer_visualizer.cpp:17-51): kind 0 diffuse colour, 1 / 2 bump-mapped normal."""
@@ -452,7 +465,7 @@ class PathTracer:
         y1 = H - 1 if y1 is None else y1
         self._chk(self._L.prt_hip_render_gbuffer(self._ctx, x0, y0, x1, y1, kind, self.seed, exposure, None, None), "prt_hip_render_gbuffer")
         img = np.zeros((H, W, 3), dtype=np.float32)
-        self._chk(self._L.prt_hip_download(self._ctx, img.ctypes.data_as(C.c_void_p), x0, y0, x1, y1), "prt_hip_download")
+        self._download(img, x0, y0, x1, y1)
         return img[y0:y1 + 1, x0:x1 + 1].copy()
 
     def render(self, samples, **kw):

@@ -13,7 +13,7 @@
 
 #define PRT_MAX_BVH 8
 #ifndef PRT_STACK_LDS
-#define PRT_STACK_LDS 12     // stack entries per lane kept in LDS (4 B each); 12 + the 4 KB of hot records let 8 blocks share a CU's LDS
+#define PRT_STACK_LDS 12     // stack entries per lane kept in LDS (4 B each): 48 KB of a 1024-thread workgroup's 78 KB (2 workgroups share a CU's 160 KB)
 #endif
 #ifndef PRT_STACK_LDS_PACKET
 #define PRT_STACK_LDS_PACKET (PRT_STACK_LDS / 2) // the same for the packet traversal (8 B each: reference + entry distance)
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void trace_loop(const DevScene& sc, Src& src, const S
 {
     const uint32_t n = src.count();
     const uint32_t lane = threadIdx.x & 63u;
-    Tracer T;
+    Tracer T{}; // every field defined in every lane (see trace_queue, prt_frame.h)
     T.ref = PRT_REF_NONE;
     T.sp = 0;
     T.m = 0;

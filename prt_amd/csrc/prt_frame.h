@@ -35,7 +35,7 @@
 #define PRT_SHADE_MIN 192u // ready groups (of the pool's 1024) that make a wave at a decision point take a shade role (48: 392-402 ms, 96: 390, 192: 386 on C3)
 #endif
 #ifndef PRT_HOT_LDS
-#define PRT_HOT_LDS 1 // keep the PRT_HOT_NODES records nearest the roots in LDS (4 KB per block)
+#define PRT_HOT_LDS 1 // keep the PRT_HOT_NODES records nearest the roots in LDS (256 records = 16 KB per workgroup of 16 waves)
 #endif
 #ifndef PRT_TRACE_PRIO
 #define PRT_TRACE_PRIO 1
@@ -65,8 +65,9 @@
 #ifndef PRT_ROLE_INLINE
 #define PRT_ROLE_INLINE __noinline__
 #endif
-#ifndef PRT_WATCHDOG_SPINS
-#define PRT_WATCHDOG_SPINS (1u << 22) // idle turns (about 0.3 us each) after which a wave gives up: ~1 s
+#ifndef PRT_WATCHDOG_TICKS
+#define PRT_WATCHDOG_TICKS 200000000ull // a wave that has found no work for this long gives up: 2 s of s_memrealtime (the constant 100 MHz counter: the
+                                        // deadline does not move with the shader clock or with how long an idle turn takes under load)
 #endif
 #define PRT_CTRL_CURSORS 256u // ctrl words: [256 + 32 * band] the 8 row cursors; behind them (PRT_WORK_WORDS..) the sticky error words: flag, watchdog reports
 #define PRT_CHUNK 64u
@@ -113,7 +114,7 @@ struct FrameArgs {
 };
 
 struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
-    // one stack column per thread: 16 references, or 8 (reference, entry distance) pairs for the packet traversal
+    // one stack column per thread: PRT_STACK_LDS (12) references, or 6 (reference, entry distance) pairs for the packet traversal
     uint32_t stack[PRT_STACK_LDS * PRT_BLOCK];
     float hot[PRT_HOT_LDS ? PRT_HOT_NODES * 16 : 4]; // DevScene::hotNodes (16-byte aligned: read with ds_read_b128)
     uint32_t coop[(PRT_BLOCK / 64) * PRT_COOP_STRIDE]; // per wave: the pair table of the cooperative leaf rounds (prt_device.h)
@@ -121,7 +122,7 @@ struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
     uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
-    uint32_t qRes[Q_COUNT];        // two shade roles: entries RESERVED behind the tail (published to qTail in reservation order)
+    uint32_t qRes[Q_COUNT];        // PRT_SHADERS shade roles: entries RESERVED behind the tail (published to qTail in reservation order)
     uint32_t lock[PRT_SHADERS];    // shade role(s)
     uint32_t ready[PRT_SHADERS];   // groups with pending == 0, per shade role (a hint for the role decision, not a correctness word)
     uint32_t live;      // groups in the pool that are not done
@@ -545,8 +546,9 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
         phase = PH_WAIT_PRIMARY;
     }
 
-    // ---- the rays of the next round go to the block's queues: lane rank by wave ballot + popcount behind the queue's tail
-    // (only the wave that holds the shade lock appends, so the tails are plain LDS words for it)
+    // ---- the rays of the next round go to the block's queues: lane rank by wave ballot + popcount behind a RESERVATION of the
+    // pass's entries (PRT_SHADERS shade roles append to the same queues: qRes is an LDS atomic, the tails are published below in
+    // reservation order)
     const bool want[Q_COUNT] = {emitPrimary, emitScatter, emitShadow && shadowPacket, emitShadow && !shadowPacket};
     const uint32_t owner = poolLocal * 8u + slot; // slot index inside the block's pool (< PRT_POOL_SLOTS)
     uint32_t emitted = 0, newTail[Q_COUNT], qBase[Q_COUNT];
@@ -623,7 +625,14 @@ __device__ __noinline__ uint32_t shade_pass(uint64_t kargs, uint32_t P, uint32_t
                 // bounded: a bug here must end as the watchdog's error, never as a hung GPU
                 uint32_t spins = 0;
                 while (lds_ld_acq(&B->qTail[q]) != qBase[q] && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(1);
-                if (spins >= (1u << 24)) lds_st(&B->abort, 1u);
+                if (spins >= (1u << 24)) {
+                    // the entries reserved before this pass's were never published: end the launch as the watchdog does (the host
+                    // gets PRT_HIP_ELAUNCH, not an incomplete image with PRT_HIP_OK) and leave the tail where it is -- moving it
+                    // would hand tracing waves the unwritten words in between
+                    lds_st(&B->abort, 1u);
+                    atomicOr(&A.ctrl[PRT_WORK_WORDS], 1u);
+                    continue;
+                }
             }
             lds_st_rel(&B->qTail[q], newTail[q]);
         }
@@ -652,7 +661,10 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     const float kFar = 2.0f * sc.radius; // path_tracer.cpp:192
     Traffic tr{};
     uint32_t overflow = 0;
-    Tracer T;
+    // Every field is written before the loop: lanes that hold no ray keep these zeros (or their last ray's values), so nothing the
+    // loop reads -- the cooperative leaf rounds hand EVERY lane's ray constants to ds_bpermute as source operands -- is ever
+    // indeterminate (reading an indeterminate value is undefined behaviour, and the optimiser once used it)
+    Tracer T{};
     T.ref = PRT_REF_NONE;
     T.sp = 0;
     T.m = 0;
@@ -1041,6 +1053,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
     }
     __syncthreads();
     uint32_t idle = 0;
+    unsigned long long idleSince = 0; // s_memrealtime at the first of the current run of idle turns
 #ifdef PRT_PROFILE
     unsigned long long tShade = 0, tTrace = 0, tIdle = 0, nShade = 0, nTrace = 0, t0 = __builtin_amdgcn_s_memtime(), tStart = t0;
 #define PROF(acc, cnt)                                            \
@@ -1125,7 +1138,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
         if (lds_ld(&B->exhausted) != 0u && lds_ld(&B->live) == 0u) break; // nothing left and nothing can arrive
         if (lds_ld(&B->abort) != 0u) break;
         __builtin_amdgcn_s_sleep(8);
-        if (++idle > PRT_WATCHDOG_SPINS) { // watchdog: a scheduling bug must end as an error code, never as a hung GPU
+        if (idle++ == 0u) idleSince = __builtin_amdgcn_s_memrealtime();
+        // watchdog: a scheduling bug must end as an error code, never as a hung GPU (the clock is read every 256th idle turn)
+        if ((idle & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - idleSince > PRT_WATCHDOG_TICKS) {
             // what the block looked like, for the host's error message (first 8 waves that give up)
             uint32_t stuck = 0, sum = 0;
             for (uint32_t i = lane; i < PRT_POOL_GROUPS; i += 64u) {

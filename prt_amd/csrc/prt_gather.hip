@@ -96,6 +96,7 @@ struct Rccl {
     int (*GetUniqueId)(rccl_unique_id*) = nullptr;
     int (*CommInitRank)(void**, int, rccl_unique_id, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr; // optional: ends a communicator whose operations may never complete
     int (*CommCount)(void*, int*) = nullptr;
     int (*CommUserRank)(void*, int*) = nullptr;
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -141,6 +142,7 @@ Rccl& rccl()
         R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
         R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
         R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+        R.CommAbort = (decltype(R.CommAbort))dlsym(R.handle, "ncclCommAbort");
         R.CommCount = (decltype(R.CommCount))sym("ncclCommCount");
         R.CommUserRank = (decltype(R.CommUserRank))sym("ncclCommUserRank");
         R.Send = (decltype(R.Send))sym("ncclSend");
@@ -159,15 +161,31 @@ Rccl& rccl()
     } while (0)
 
 // Inside ncclGroupStart .. ncclGroupEnd: a failing call must not leave the group open (every later RCCL call of this thread
-// would be queued into it and never run) -- close it, then report the FIRST error.
-#define RCCL_TRY_IN_GROUP(R, call)                                                                            \
+// would be queued into it and never run) -- close it, then report the FIRST error.  Closing the group also LAUNCHES whatever was
+// queued before the failure (a root that queued k of n receives now waits for those k peers), and RCCL leaves a communicator
+// in an error state after a failed operation: the context marks it broken, every later gather on it is refused, and
+// prt_hip_comm_init / _adopt / _destroy end it with ncclCommAbort (which does not wait for operations that cannot complete).
+#define RCCL_TRY_IN_GROUP(R, c, call)                                                                         \
     do {                                                                                                      \
         int r_ = (call);                                                                                      \
         if (r_ != 0) {                                                                                        \
             (void)(R).GroupEnd();                                                                             \
+            (c)->commBroken = true;                                                                           \
             return prt_fail(PRT_HIP_ECOMM, std::string(#call) + ": " + (R).GetErrorString(r_));               \
         }                                                                                                     \
     } while (0)
+
+// Ends the context's communicator if the context owns it: a broken one by ncclCommAbort where the library has it.
+static void drop_comm(Rccl& R, prt_hip_ctx* c)
+{
+    if (c->comm && c->commOwned) {
+        if (c->commBroken && R.CommAbort) (void)R.CommAbort(c->comm);
+        else if (R.CommDestroy) (void)R.CommDestroy(c->comm);
+    }
+    c->comm = nullptr;
+    c->commOwned = false;
+    c->commBroken = false;
+}
 
 int need_rccl(Rccl** out)
 {
@@ -185,12 +203,7 @@ void prt_gather_release(prt_hip_ctx* c)
     if (c->stageBuf) (void)hipFree(c->stageBuf);
     c->packBuf = c->stageBuf = nullptr;
     c->packFloats = c->stageFloats = 0;
-    if (c->comm && c->commOwned) {
-        Rccl& R = rccl();
-        if (R.CommDestroy) (void)R.CommDestroy(c->comm);
-    }
-    c->comm = nullptr;
-    c->commOwned = false;
+    if (c->comm) drop_comm(rccl(), c);
 }
 
 extern "C" {
@@ -216,8 +229,7 @@ int prt_hip_comm_init(prt_hip_ctx* c, const void* id, int rank, int nranks)
     int rc = need_rccl(&R);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->comm && c->commOwned) (void)R->CommDestroy(c->comm);
-    c->comm = nullptr;
+    drop_comm(*R, c);
     rccl_unique_id u;
     memcpy(&u, id, sizeof(u));
     void* comm = nullptr;
@@ -239,7 +251,7 @@ int prt_hip_comm_adopt(prt_hip_ctx* c, void* ncclComm)
     int n = 0, r = 0;
     RCCL_TRY(*R, R->CommCount(ncclComm, &n));
     RCCL_TRY(*R, R->CommUserRank(ncclComm, &r));
-    if (c->comm && c->commOwned) (void)R->CommDestroy(c->comm);
+    drop_comm(*R, c);
     c->comm = ncclComm;
     c->commOwned = false;
     c->commRank = r;
@@ -255,11 +267,16 @@ int prt_hip_comm_destroy(prt_hip_ctx* c)
         int rc = need_rccl(&R);
         if (rc) return rc;
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        RCCL_TRY(*R, R->CommDestroy(c->comm));
+        if (c->commBroken) {
+            drop_comm(*R, c); // (no stream synchronisation first: an operation of a broken communicator may never complete)
+        } else {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            RCCL_TRY(*R, R->CommDestroy(c->comm));
+        }
     }
     c->comm = nullptr;
     c->commOwned = false;
+    c->commBroken = false;
     c->commSize = 0;
     return PRT_HIP_OK;
 }
@@ -272,6 +289,8 @@ int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
         snprintf(where, sizeof(where), " (ctx %p, size %d)", (void*)c, c->commSize);
         return prt_fail(PRT_HIP_ESTATE, std::string("no communicator: call prt_hip_comm_init or prt_hip_comm_adopt first") + where);
     }
+    if (c->commBroken)
+        return prt_fail(PRT_HIP_ECOMM, "the communicator is unusable after a failed ncclSend / ncclRecv: call prt_hip_comm_init (or prt_hip_comm_adopt) again on every rank");
     if (root < 0 || root >= c->commSize) return prt_fail(PRT_HIP_EINVAL, "root outside the communicator");
     if (!c->haveCamera || c->lastTile == 0) return prt_fail(PRT_HIP_ESTATE, "nothing rendered yet");
     if (c->lastNranks != (uint32_t)c->commSize || c->lastRank != (uint32_t)c->commRank)
@@ -298,7 +317,7 @@ int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
             if ((rc = ensure_floats(&c->packBuf, &c->packFloats, mine * tileFloats))) return rc;
             launch_pack(false, d_rgb, c->packBuf, W, H, T, me, n, mine, s);
             RCCL_TRY(*R, R->GroupStart());
-            if (mine) RCCL_TRY_IN_GROUP(*R, R->Send(c->packBuf, mine * tileFloats, kNcclFloat, root, c->comm, s));
+            if (mine) RCCL_TRY_IN_GROUP(*R, c, R->Send(c->packBuf, mine * tileFloats, kNcclFloat, root, c->comm, s));
             RCCL_TRY(*R, R->GroupEnd());
         } else {
             // staged tiles of rank r start at off[r]; the root's own tiles are already where they belong
@@ -308,7 +327,7 @@ int prt_hip_gather_rccl(prt_hip_ctx* c, float* d_rgb, int root, void* stream)
             RCCL_TRY(*R, R->GroupStart());
             for (uint32_t r = 0; r < n; r++) {
                 const size_t cnt = off[r + 1] - off[r];
-                if (r != me && cnt) RCCL_TRY_IN_GROUP(*R, R->Recv(c->stageBuf + off[r], cnt, kNcclFloat, (int)r, c->comm, s));
+                if (r != me && cnt) RCCL_TRY_IN_GROUP(*R, c, R->Recv(c->stageBuf + off[r], cnt, kNcclFloat, (int)r, c->comm, s));
             }
             RCCL_TRY(*R, R->GroupEnd());
             for (uint32_t r = 0; r < n; r++)

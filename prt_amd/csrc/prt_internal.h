@@ -64,6 +64,7 @@ struct prt_hip_ctx {
     // image gather (prt_gather.hip): tile-major staging buffers and the RCCL communicator
     void* comm = nullptr;       // ncclComm_t
     bool commOwned = false;     // created by prt_hip_comm_init (destroyed with the context) or adopted from the host
+    bool commBroken = false;    // a send / receive failed: the communicator is refused until it is replaced (prt_gather.hip)
     int commRank = 0, commSize = 0;
     float* packBuf = nullptr;   // this rank's tiles, tile-major
     size_t packFloats = 0;
@@ -77,6 +78,8 @@ struct prt_hip_ctx {
 };
 
 
+// prt_gather.hip: frees the staging buffers and an owned communicator
 void prt_gather_release(prt_hip_ctx* c);
-// 0, or the error code of a launch since the last prt_hip_get_stats whose image must not be trusted (the context's stream must be idle)
-int prt_sticky_error(prt_hip_ctx* c, bool clear); // prt_gather.hip: frees the staging buffers and an owned communicator
+// prt_kernels.hip: 0, or the error code of a launch since the last prt_hip_get_stats whose image must not be trusted (the context's
+// stream must be idle); `clear` consumes it (prt_hip_get_stats), download / gather only report it
+int prt_sticky_error(prt_hip_ctx* c, bool clear);

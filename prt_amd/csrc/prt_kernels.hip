@@ -251,7 +251,7 @@ struct ArraySrc {
     {
         prt_hit o;
         // the device names a hit triangle by its leaf-order index; the reference's primId is that triangle's index in its mesh
-        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = (h.t != -1.0f) ? gld(A->sc.triPrim + h.primId) : h.primId; o.meshId = h.meshId;
+        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = (h.t != -1.0f && h.t == h.t) ? gld(A->sc.triPrim + h.primId) : h.primId; // (a NaN limit keeps hit.t NaN: no triangle was recorded) o.meshId = h.meshId;
         A->hits[i] = o;
     }
     __device__ __forceinline__ void store_occ(uint32_t i, bool occ) const

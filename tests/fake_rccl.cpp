@@ -151,6 +151,15 @@ int ncclCommDestroy(void* comm)
     return kSuccess;
 }
 
+static std::atomic<int> abortedComms{0};
+int ncclCommAbort(void* comm)
+{
+    abortedComms++;
+    delete (Comm*)comm;
+    return kSuccess;
+}
+int fake_rccl_aborted_comms() { return abortedComms.load(); }
+
 int ncclCommCount(void* comm, int* n)
 {
     *n = ((Comm*)comm)->n;

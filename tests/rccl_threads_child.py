@@ -108,7 +108,19 @@ def main():
             except prt_amd.PrtError as e:
                 assert "internal error" in str(e), str(e)
             assert fake.fake_rccl_open_groups() == 0, "prt_hip_gather_rccl returned with the RCCL group still open"
-        in_threads([lambda t=t: t.gather_rccl(root=0) for t in ranks])  # and the communicator still works
+            # RCCL leaves a communicator in an error state after a failed operation: the context refuses it from now on ...
+            try:
+                ranks[who].gather_rccl(root=0)
+                raise AssertionError("a gather on a broken communicator was let through")
+            except prt_amd.PrtError as e:
+                assert "unusable after a failed" in str(e), str(e)
+        # ... until every rank replaces it (the broken ones end by ncclCommAbort), and the new one works
+        aborted0 = fake.fake_rccl_aborted_comms()
+        uid = prt_amd.comm_unique_id()
+        for i, t in enumerate(ranks):
+            t.comm_init(uid, i, 2)
+        assert fake.fake_rccl_aborted_comms() - aborted0 == 2
+        in_threads([lambda t=t: t.gather_rccl(root=0) for t in ranks])
         one = prt_amd.PathTracer(device=0, max_depth=4, seed=777)
         one.upload_scene(scene)
         one.set_camera(camera)

@@ -467,6 +467,35 @@ def test_an_earlier_frames_error_survives_later_renders(tracer, c1):
         t.close()
 
 
+def test_an_overflow_frame_raises_once_and_the_next_render_is_clean(c1):
+    """prt_hip_download reports a sticky error without clearing it, so render() / trace_block() / gbuffer() used to
+    fail for ever after one bad frame.  They consume it now: the overflow frame raises, the same tracer then renders a clean
+    scene, whose image equals a fresh tracer's."""
+    import ctypes as C
+    sd, keep = _chain_scene_desc(80)
+    t = prt_amd.PathTracer(device=0, max_depth=4, seed=1)
+    try:
+        t._chk(t._L.prt_hip_upload_scene(t._ctx, C.byref(sd)), "upload")
+        t.set_camera(prt_amd.Camera().create((0.0, 0.2, 0.2), (1.0, 0.0, 0.0), 32, 32))
+        with pytest.raises(prt_amd.PrtError, match="64 stack entries"):
+            t.render(8)
+        scene, camera, _ = c1
+        t.upload_scene(scene)
+        t.set_camera(camera)
+        a = t.trace_block(0, 0, 63, 63, 8)     # clean again: nothing left over from the bad frame
+        g = t.gbuffer(1, 0, 0, 63, 63)
+        assert np.isfinite(g).all()
+        t2 = prt_amd.PathTracer(device=0, max_depth=4, seed=1)
+        try:
+            t2.upload_scene(scene)
+            t2.set_camera(camera)
+            assert_bits_equal(a, t2.trace_block(0, 0, 63, 63, 8), "after an overflow frame")
+        finally:
+            t2.close()
+    finally:
+        t.close()
+
+
 def test_large_scene_4k_one_launch_matches_oracle_tiles(tracer):
     """C5-class at its BASELINE resolution: 3840x2160 (8.3 M pixel groups, ONE launch of the frame kernel: its per-launch
     state does not grow with the image), a 1 M-triangle emissive scene without directional light, depth cap 12, exposure 64;

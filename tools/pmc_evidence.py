@@ -36,7 +36,8 @@ fetch, write = g("FETCH_SIZE") * 1024, g("WRITE_SIZE") * 1024
 import prt_amd
 d = {
     "workload": workload, "frame": frame + ", one GPU", "kernel": "frame_kernel<false, false>",
-    "source_sha16": stamp,  # (tools/pmc_frame.py prints the loaded library's stamp into each pass's log) "kernel_ms_under_profiler_median": kernel_ms, "rays_per_frame": rays,
+    # (tools/pmc_frame.py prints the loaded library's stamp into each pass's log)
+    "source_sha16": stamp, "kernel_ms_under_profiler_median": kernel_ms, "rays_per_frame": rays,
     "counters_raw": {k: C[k] for k in sorted(C)},
     "derived": {
         "lanes_active_per_valu_instruction": g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU"),
@@ -56,6 +57,13 @@ d = {
         "l2_requests_per_ray": g("TCC_REQ_sum") / rays,
         "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
         "l2_misses_per_ray": g("TCC_MISS_sum") / rays,
+        # the roofs that can bind this kernel, each a measured quantity <= 1:
+        #   useful share of the vector ALU = busy fraction x lanes that do work per instruction / 64
+        "valu_useful_frac (valu_busy_frac x lanes_active / 64)": g("SQ_INSTS_VALU") * 3.07 / 1024.0 / (clock * kernel_ms * 1e-3) * g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU") / 64.0,
+        #   L2 misses per second against the measured ceiling of dependent 64-byte gathers from beyond the caches at this kernel's
+        #   occupancy (profiles/r03_rec_gather.txt: 52.9 G/s from a 2 GB table, 55.9 G/s from 256 MB)
+        "l2_miss_rate_Gps": g("TCC_MISS_sum") / (kernel_ms * 1e-3) / 1e9,
+        "gather_roof_frac (l2_miss_rate / 52.9 G per second)": g("TCC_MISS_sum") / (kernel_ms * 1e-3) / 52.9e9,
     },
     "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes_per_frame": fetch + write,
     "traffic_GBps": (fetch + write) / (kernel_ms * 1e-3) / 1e9, "hbm_frac_of_8TBps": (fetch + write) / (kernel_ms * 1e-3) / 8e12,
