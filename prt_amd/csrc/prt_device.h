@@ -189,6 +189,7 @@ struct Traffic {
     // and those that came from the spill area in HBM (per lane)
     unsigned long long pNodeRounds, pNodeLanes, pLeafRounds, pLeafLanes, pTri2Lanes, pPops, pDeepPops;
     unsigned long long pNodeWaitLeaf, pNodeDone, pNodeNoRay, pLeafWaitNode, pLeafDone, pLeafNoRay, pLeafUpdates; // lanes that sit a round out, by reason (wave-uniform)
+    unsigned long long pNodeDistinct; // distinct records the lanes of the node rounds asked for (wave-uniform): the coherence of a wave's rays
 #endif
 };
 
@@ -1071,6 +1072,14 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
 #endif
 #ifdef PRT_PROFILE
         if (doNode) {
+            { // distinct records of this round: one per group of lanes that stand on the same node
+                unsigned long long m = __ballot(onNode);
+                while (m) {
+                    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)T.ref, (int)__builtin_ctzll(m));
+                    m &= ~__ballot(onNode && T.ref == r);
+                    tr.pNodeDistinct++;
+                }
+            }
             tr.pNodeRounds++;
             tr.pNodeLanes += nNode;
             tr.pNodeWaitLeaf += nLeaf;

@@ -912,6 +912,7 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[68 + MODE * 8], tr.pLeafDone);
         atomicAdd(&C[69 + MODE * 8], tr.pLeafNoRay);
         atomicAdd(&C[70 + MODE * 8], tr.pLeafUpdates);
+        atomicAdd(&C[71 + MODE * 8], tr.pNodeDistinct);
         atomicAdd(&C[37 + MODE * 8], pRefillLanes);
         atomicAdd(&C[38 + MODE * 8], pRefills);
         atomicAdd(&C[16 + MODE * 3], pTurns);

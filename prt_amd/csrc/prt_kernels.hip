@@ -251,7 +251,10 @@ struct ArraySrc {
     {
         prt_hit o;
         // the device names a hit triangle by its leaf-order index; the reference's primId is that triangle's index in its mesh
-        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k; o.primId = (h.t != -1.0f && h.t == h.t) ? gld(A->sc.triPrim + h.primId) : h.primId; // (a NaN limit keeps hit.t NaN: no triangle was recorded) o.meshId = h.meshId;
+        // (a NaN limit keeps hit.t NaN: no triangle was recorded and primId is not an index)
+        o.t = h.t; o.i = h.i; o.j = h.j; o.k = h.k;
+        o.primId = (h.t != -1.0f && h.t == h.t) ? gld(A->sc.triPrim + h.primId) : h.primId;
+        o.meshId = h.meshId;
         A->hits[i] = o;
     }
     __device__ __forceinline__ void store_occ(uint32_t i, bool occ) const
@@ -858,7 +861,9 @@ static int frame_blocks(prt_hip_ctx* c)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, frame_kernel<false, false>, PRT_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
         // No block waits for another one, so a block the hardware admits later than the query says only starts later.
         c->frameBlocksPerCU = std::min(nb, 8);
+#ifdef PRT_TUNING_ENV // tuning builds only (tools/build_variants.py): the product reads no tuning variable
         if (const char* e = getenv("PRT_FRAME_BPC")) c->frameBlocksPerCU = std::max(1, std::min(8, atoi(e)));
+#endif
     }
     return c->computeUnits * c->frameBlocksPerCU;
 }
@@ -911,7 +916,10 @@ static int render_frame_kernel(prt_hip_ctx* c, FrameArgs& A, uint64_t totalWork,
     // rows are in flight at once (a row that starts late costs a whole chain of rounds), spread evenly over the blocks
     A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (A.totalChunks + blocks - 1) / blocks));
     A.spreadRows = (A.totalChunks < (uint64_t)blocks * PRT_POOL_CHUNKS * 2 && totalWork % PRT_CHUNK == 0) ? 1u : 0u;
+#ifdef PRT_TUNING_ENV
     if (const char* e = getenv("PRT_SPREAD")) A.spreadRows = atoi(e) && totalWork % PRT_CHUNK == 0;
+    if (const char* e = getenv("PRT_ROWS")) A.rowsPerBlock = std::max<uint32_t>(1, std::min<uint32_t>(PRT_POOL_CHUNKS, (uint32_t)atoi(e)));
+#endif
     int rc = ensure_launch_resources(c, resident);
     if (rc) return rc;
     A.spill = c->spill;
@@ -1148,8 +1156,8 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
             const unsigned long long* q = h + 32 + 8 * m;
             const unsigned long long* w = h + 64 + 8 * m;
             const double nr = (double)(q[0] ? q[0] : 1), lr = (double)(q[2] ? q[2] : 1);
-            fprintf(stderr, "  mode %d lanes sitting out: node rounds %.1f on a leaf, %.1f finished, %.1f without a ray; leaf rounds %.1f on a node, %.1f finished, %.1f without a ray; %.2f hit-update turns per leaf round\n",
-                    m, w[0] / nr, w[1] / nr, w[2] / nr, w[3] / lr, w[4] / lr, w[5] / lr, w[6] / lr);
+            fprintf(stderr, "  mode %d lanes sitting out: node rounds %.1f on a leaf, %.1f finished, %.1f without a ray; leaf rounds %.1f on a node, %.1f finished, %.1f without a ray; %.2f hit-update turns per leaf round; %.1f distinct records per node round\n",
+                    m, w[0] / nr, w[1] / nr, w[2] / nr, w[3] / lr, w[4] / lr, w[5] / lr, w[6] / lr, w[7] / nr);
         }
         for (int m = 0; m < 4; m++) {
             const unsigned long long* w = h + 96 + 4 * m;
@@ -1227,12 +1235,20 @@ int prt_hip_trace_rays(prt_hip_ctx* c, int mode, uint32_t n, const float* org, c
     HIP_TRY(hipMemsetAsync(c->work, 0, PRT_WORK_WORDS * sizeof(uint32_t), c->stream));
     RaysArgs A{c->sc, n, dorg.as<float>(), ddir.as<float>(), maxT, dh.as<prt_hit>(), c->work, c->spill, c->spillThreads, c->counters};
     blocks = std::min<uint32_t>(blocks, (uint32_t)c->spillThreads / PRT_BLOCK);
+    // timed like a render (prt_hip_get_stats reports it as kernelMs): tools/ray_order_experiment.py compares orders of one batch
+    if (c->ringUsed == PRT_TIMING_RING) fold_timing(c);
+    if (!c->evT0[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT0[c->ringUsed]));
+    if (!c->evT1[c->ringUsed]) HIP_TRY(hipEventCreate(&c->evT1[c->ringUsed]));
+    hipEvent_t ev0 = c->evT0[c->ringUsed], ev1 = c->evT1[c->ringUsed];
+    c->ringUsed++;
+    HIP_TRY(hipEventRecord(ev0, c->stream));
     if (mode == 0) hipLaunchKernelGGL(rays_kernel<PRT_MODE_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     else if (mode == 1) hipLaunchKernelGGL(rays_kernel<PRT_MODE_PACKET>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     else if (mode == 2) hipLaunchKernelGGL(rays_kernel<PRT_MODE_OCC_SINGLE>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     else hipLaunchKernelGGL(rays_kernel<PRT_MODE_OCC_PACKET>, dim3(blocks), dim3(PRT_BLOCK), 0, c->stream, A);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(PRT_HIP_ELAUNCH, std::string("rays_kernel launch: ") + hipGetErrorString(le));
+    HIP_TRY(hipEventRecord(ev1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(prt_hit), hipMemcpyDeviceToHost));
     c->timed = false;

@@ -6,6 +6,7 @@ on the same machine: the oracle needs hours of CPU for this frame (44 G rays), a
     c5_split_check.py fixture IN.npz OUT.npz CPU.log...  the digests of the tile rows the `cpu` runs reported as equal in EVERY tile -- the
                                                    oracle's output for those rows (equal SHA-256 = equal bytes) -- as the
                                                    fixture of the GPU suite (tests/golden/c5_tile_rows.npz)
+    c5_split_check.py cpu IN.npz MINUTES [ROW0 [SKIP.npz]]  (SKIP.npz: a fixture whose rows are done already and are left out)
     c5_split_check.py cpu IN.npz MINUTES [ROW0]    anywhere: the oracle (all threads given by PRT_ORACLE_THREADS, default all cores)
                                                    renders tile rows from ROW0 (default: the middle of the image) outwards for
                                                    MINUTES and compares every finished tile with the GPU's digest; one line per
@@ -86,6 +87,9 @@ def main():
         for r in (row0 + d, row0 - d):
             if 0 <= r < tiles_y:
                 order.append(r)
+    if len(sys.argv) > 5:
+        have = set(int(r) for r in np.load(sys.argv[5])["rows"])
+        order = [r for r in order if r not in have]
     t0 = time.time()
     equal = differing = 0
     rays = 0

@@ -3,8 +3,17 @@ smaller launch loses.  Diagnostic only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import prt_amd
-W, H, spp, depth = 1920, 1080, 64, 8
-scene, camera, exposure = prt_amd.setup_atrium_standin(W, H, tris=262000, seed=1)
+if len(sys.argv) > 1:
+    prt_amd.LIB_PATH = sys.argv[1]  # a tuning variant (with -DPRT_TUNING_ENV it honours PRT_SPREAD / PRT_ROWS)
+wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
+if wl == "c3":
+    W, H, spp, depth, kw = 1920, 1080, 64, 8, dict(tris=262000, seed=1)
+elif wl == "c4":
+    W, H, spp, depth, kw = 1920, 1080, 64, 14, dict(tris=2500000, seed=4)
+else:
+    W, H, spp, depth, kw = 3840, 2160, 64, 12, dict(tris=5000000, seed=5, emissive_fraction=0.1, light=False)
+scene, camera, exposure = prt_amd.setup_atrium_standin(W, H, **kw)
+print(f"{wl} {W}x{H} {spp} spp; library {prt_amd.loaded_source_sha16()}; PRT_SPREAD={os.environ.get('PRT_SPREAD', '(product rule)')}", flush=True)
 tr = prt_amd.PathTracer(device=0, max_depth=depth, seed=12345)
 tr.upload_scene(scene); tr.set_camera(camera)
 full = None
