@@ -189,6 +189,7 @@ struct Traffic {
     // and those that came from the spill area in HBM (per lane)
     unsigned long long pNodeRounds, pNodeLanes, pLeafRounds, pLeafLanes, pTri2Lanes, pPops, pDeepPops;
     unsigned long long pNodeWaitLeaf, pNodeDone, pNodeNoRay, pLeafWaitNode, pLeafDone, pLeafNoRay, pLeafUpdates; // lanes that sit a round out, by reason (wave-uniform)
+    unsigned long long pDirectInt, pPopInt; // (per lane) steps that leave the lane on an internal record outside the hot set: reached by descending from its parent / by a pop
     unsigned long long pNodeDistinct; // distinct records the lanes of the node rounds asked for (wave-uniform): the coherence of a wave's rays
 #endif
 };
@@ -1095,7 +1096,16 @@ __device__ __forceinline__ void trace_step_phase(const DevScene& sc, Tracer& T, 
         }
 #endif
         if (doNode) {
+#ifdef PRT_PROFILE
+            const int sp0 = T.sp;
+#endif
             if (onNode) tracer_node<MODE, COUNT>(sc, T, st, tr, overflow);
+#ifdef PRT_PROFILE
+            if (onNode && ref_is_internal(T.ref) && !(T.ref & PRT_REF_HOT)) {
+                if (T.sp < sp0) tr.pPopInt++;
+                else tr.pDirectInt++;
+            }
+#endif
         } else if (PRT_COOP_LEAF && !COUNT) {
             tracer_leaf_coop<MODE>(sc, T, onLeaf, st, tr);
         } else {

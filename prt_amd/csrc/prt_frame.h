@@ -56,6 +56,17 @@
 #ifndef PRT_CLAIM
 #define PRT_CLAIM 128u // queue entries a wave reserves at a time
 #endif
+// Which queue a wave at a decision point traces (round 4).  Rounds 2-3: the fullest -- so every wave that came free took the scatter queue
+// and they ran it dry together while hundreds of occlusion and primary rays waited for a wave (profiles/r04_experiments.txt E).  Now
+// the queue with the most rays PER WAVE that would then be on it: score = 1 + len * PRT_BALANCE / (waves on it * PRT_BALANCE_W +
+// PRT_BALANCE); the waves spread over the queues in proportion to their lengths and a queue without a wave gets the next one.
+// C3 370 -> 357 ms; weights 8 .. 64 alike; PRT_BALANCE 0 = the fullest queue.
+#ifndef PRT_BALANCE
+#define PRT_BALANCE 1
+#endif
+#ifndef PRT_BALANCE_W
+#define PRT_BALANCE_W 16
+#endif
 #ifndef PRT_DRAIN_READY
 #define PRT_DRAIN_READY 1024u // ready groups at which tracing waves stop refilling (so that one of them comes free to shade): the whole pool
 #endif
@@ -122,6 +133,7 @@ struct __attribute__((aligned(16))) BlockState { // LDS, one per workgroup
     uint32_t readyList[PRT_POOL_GROUPS]; // the shade role's work list of one sweep
     uint32_t chunkLive[PRT_POOL_CHUNKS]; // groups of the row that are not done; 0 = the row can take new work
     uint32_t qTail[Q_COUNT], qHead[Q_COUNT];
+    uint32_t qWaves[Q_COUNT];      // waves tracing each queue right now (PRT_BALANCE: the decision point shares the waves out by queue length)
     uint32_t qRes[Q_COUNT];        // PRT_SHADERS shade roles: entries RESERVED behind the tail (published to qTail in reservation order)
     uint32_t lock[PRT_SHADERS];    // shade role(s)
     uint32_t ready[PRT_SHADERS];   // groups with pending == 0, per shade role (a hint for the role decision, not a correctness word)
@@ -881,6 +893,12 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
     __builtin_amdgcn_s_setprio(0);
 #ifdef PRT_PROFILE
     unsigned long long pops = tr.pPops, deepPops = tr.pDeepPops; // per lane: summed over the wave by all its lanes
+    unsigned long long directInt = tr.pDirectInt, popInt = tr.pPopInt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        directInt += (unsigned long long)__shfl_xor((long long)directInt, o, 64);
+        popInt += (unsigned long long)__shfl_xor((long long)popInt, o, 64);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         pops += (unsigned long long)__shfl_xor((long long)pops, o, 64);
@@ -913,6 +931,8 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[69 + MODE * 8], tr.pLeafNoRay);
         atomicAdd(&C[70 + MODE * 8], tr.pLeafUpdates);
         atomicAdd(&C[71 + MODE * 8], tr.pNodeDistinct);
+        atomicAdd(&C[120], directInt);
+        atomicAdd(&C[121], popInt);
         atomicAdd(&C[37 + MODE * 8], pRefillLanes);
         atomicAdd(&C[38 + MODE * 8], pRefills);
         atomicAdd(&C[16 + MODE * 3], pTurns);
@@ -1039,6 +1059,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
     if (tid < PRT_POOL_CHUNKS) B->chunkLive[tid] = 0;
     if (tid < Q_COUNT) {
         B->qTail[tid] = 0;
+        B->qWaves[tid] = 0;
         B->qRes[tid] = 0;
         B->qHead[tid] = 0;
     }
@@ -1077,8 +1098,15 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
             const int32_t d = (int32_t)(lds_ld_acq(&B->qTail[q]) - lds_ld(&B->qHead[q]));
             const uint32_t len = d > 0 ? (uint32_t)d : 0u;
             total += len;
-            if (len > bestLen) {
-                bestLen = len;
+#if PRT_BALANCE
+            // rays queued per wave that would then be on the queue: waves spread over the queues in proportion to their lengths instead of
+            // all taking the fullest one and running it dry together
+            const uint32_t score = len == 0u ? 0u : 1u + (len * PRT_BALANCE) / (lds_ld(&B->qWaves[q]) * PRT_BALANCE_W + PRT_BALANCE);
+#else
+            const uint32_t score = len;
+#endif
+            if (score > bestLen) {
+                bestLen = score;
                 best = (uint32_t)q;
             }
         }
@@ -1125,10 +1153,12 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_FRAME_WAVES) void frame_kernel(const
         }
         if (!did && total > 0u) {
             best = bcast0(best);
+            if (PRT_BALANCE && lane == 0) lds_add(&B->qWaves[best], 1u);
             if (best == Q_PRIMARY) trace_queue<PRT_MODE_PACKET, COUNT>(kargs);
             else if (best == Q_SCATTER) trace_queue<PRT_MODE_SINGLE, COUNT>(kargs);
             else if (best == Q_OCC_PACKET) trace_queue<PRT_MODE_OCC_PACKET, COUNT>(kargs);
             else trace_queue<PRT_MODE_OCC_SINGLE, COUNT>(kargs);
+            if (PRT_BALANCE && lane == 0) lds_sub(&B->qWaves[best], 1u);
             did = true;
             PROF(tTrace, nTrace++);
         }

@@ -1171,6 +1171,8 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
         if (h[118])
             fprintf(stderr, "  shade passes with a bounce: %.1f M, %.1f of 64 lanes carry a path through it; the shade role is held %.2f of a block's time (sum of its waves' shade shares)\n",
                     h[118] / 1e6, (double)h[119] / h[118], 4.0 * h[8] / h[13]);
+        fprintf(stderr, "  node steps that leave a lane on an internal record outside the hot set: %.2f G by descending from the parent, %.2f G by a pop (%.2f of them direct)\n",
+                h[120] / 1e9, h[121] / 1e9, (double)h[120] / (double)(h[120] + h[121] ? h[120] + h[121] : 1));
         fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));
     }
