@@ -67,7 +67,9 @@ def algorithmic_split(st):
 
 # Measured ceiling of dependent 64-byte record gathers from beyond the L2 at this kernel's occupancy (8 waves per SIMD), by the size of
 # the table gathered from: tools/rec_gather.hip, profiles/r03_rec_gather.txt (G records per second of the whole chip)
-GATHER_ROOF = ((64e6, 81.1, "a 16 MB table: inside the Infinity Cache"), (512e6, 55.9, "a 256 MB table"), (float("inf"), 52.9, "a 2 GB table: DRAM row activations"))
+# and profiles/r04_rec_gather_sizes.txt (the sizes in between: the Infinity Cache stops helping random gathers well below its 256 MB)
+GATHER_ROOF = ((16.8e6, 80.5, "a 16 MB table: inside the Infinity Cache"), (33.6e6, 68.5, "a 32 MB table"), (67.2e6, 60.6, "a 64 MB table"),
+               (134.3e6, 57.2, "a 128 MB table"), (268.5e6, 55.4, "a 256 MB table"), (float("inf"), 52.9, "a 2 GB table: DRAM row activations"))
 
 
 def binding_roof(ev, kernel_ms, tree_bytes):
@@ -363,10 +365,10 @@ def main():
         traffic_rate = traffic_bytes / (kernel_ms * 1e-3) / 1e9 if ev else None
         value = rays_per_step * args.steps / dt / 1e6
         name, cus = tracer.device_info()
-        # tree bytes of the workload (64-byte records of the internal nodes + 36-byte triangle slots, ~1.12 slots per triangle with the
-        # padded leaf blocks): which of the measured gather ceilings applies
-        tris = int(kw.get("tris", 0)) or 16000
-        tree_bytes = tris * (36 * 1.12 + 64 * 0.35)
+        # bytes of the tree the traversals gather from (64-byte records of the internal nodes -- (nodes - 1) / 2 of a binary tree -- and
+        # 36-byte triangle slots, ~1.12 slots per triangle with the padded leaf blocks): which of the measured gather ceilings applies
+        sd = scene.describe().contents
+        tree_bytes = sum((sd.meshes[i].nodeCount - 1) // 2 * 64 + sd.meshes[i].primCount * 36 * 1.12 for i in range(sd.meshCount))
         bind, roofs = binding_roof(ev, kernel_ms, tree_bytes) if ev else (None, None)
         out = {
             "metric": "Mray/s (primary+secondary) at 1080p/64spp; 1/2/4/8-GPU scaling",
@@ -385,6 +387,7 @@ def main():
             # SURVEY 8d's contract figure, which is not a fraction of anything (it exceeds 1 on this configuration)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": roofs[bind]["frac"] if ev else None, "frac_of": (bind + ": " + roofs[bind]["formula"]) if ev else None, "roofs": roofs,
+                         "tree_bytes": int(tree_bytes),
                          "algorithmic_frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic_rate, "hbm_frac": (traffic_rate / HBM_PEAK_GBS) if traffic_rate else None,
                          "traffic_bytes_per_launch": traffic_bytes, "traffic_source": ev["file"] if ev else None,

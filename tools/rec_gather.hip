@@ -6,6 +6,7 @@
 // rate of a 64-byte record (the rate of L2 MISSES is the roof of the large scenes) or at half of it?
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 
 __device__ __forceinline__ uint32_t xs(uint32_t x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
@@ -50,10 +51,21 @@ static void run(const float4* tab, size_t tableBytes, float* out)
            n / (ms * 1e6), n * USED / (ms * 1e6), hipGetErrorString(hipGetLastError()));
 }
 
-int main()
+int main(int argc, char** argv)
 {
     float* out;
     hipMalloc(&out, 256 * 8 * 256 * 4);
+    if (argc > 1) { // rec_gather MB MB ... : 64-byte records only, tables of the given sizes (powers of two): where does the Infinity Cache stop helping?
+        for (int a = 1; a < argc; a++) {
+            const size_t bytes = (size_t)atoi(argv[a]) << 20;
+            float4* tab;
+            if (hipMalloc(&tab, bytes) != hipSuccess) { printf("no %s MB\n", argv[a]); continue; }
+            hipMemset(tab, 0, bytes);
+            run<64, 64>(tab, bytes, out);
+            hipFree(tab);
+        }
+        return 0;
+    }
     for (size_t mb : {16u, 256u, 2048u}) {
         const size_t bytes = mb << 20;
         float4* tab;
