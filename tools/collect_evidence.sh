@@ -19,5 +19,5 @@ python - <<PY
 import json
 for w in ("c3", "c2", "c1", "c4"):
     d = json.load(open("gpurun_out/${P}_bench_%s.json" % w))
-    print(w, round(d["value"], 1), "Mray/s", round(d["ms_per_step"], 2), "ms", "frac", round(d["roofline"]["frac"], 3), "hbm_frac", d["roofline"]["hbm_frac"], "cpu", d.get("cpu_baseline", {}).get("value"))
+    print(w, round(d["value"], 1), "Mray/s", round(d["ms_per_step"], 2), "ms", "frac", d["roofline"]["frac"], "of", (d["roofline"]["frac_of"] or "-")[:24], "hbm_frac", d["roofline"]["hbm_frac"], "cpu", d.get("cpu_baseline", {}).get("value"))
 PY
