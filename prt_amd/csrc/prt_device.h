@@ -47,7 +47,11 @@
 // bump:   3 x float4 per triangle slot {dp01 duv01.x} {dp02 duv01.y} {duv02.xy 0 0}
 // mats:   5 x float4 per material {kd reflType} {ke alphaTest} {diffuseTex bumpTex 0 0} {descriptor of the diffuse map} {... of the bump map}
 //         (descriptor = {byte offset, width, height, component}, as in texDesc)
-// alpha:  2 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex 0}
+// alpha:  3 x float4 per alpha-tested leaf triangle {uv0 uv1} {uv2 tex classWord} {descriptor of the texture: byte offset, width, height, component}
+//         (classWord = first word of the texture's cell classes in alphaClass: the record, not a table, says where everything is)
+// alphaClass: 2 bits per bilinear CELL (x0, y0) of every alpha-tested texture, 16 cells per word: 1 = the cell's four texels all have
+//         alpha >= 128 (the blend of Texture::testAlpha exceeds 127 whatever the weights), 2 = all four <= 126 (it cannot), 0 = mixed:
+//         the cooperative leaf rounds decide most alpha tests from one word that stays in the L2 instead of four texel fetches
 struct DevScene {
     const float4* wnodes;
     const float4* hotNodes; // PRT_HOT_NODES records (4 x float4 each): copies of the records that PRT_REF_HOT references name
@@ -58,6 +62,7 @@ struct DevScene {
     const float4* bump;
     const float4* mats;
     const float4* alpha;
+    const uint32_t* alphaClass;
     const uint4* texDesc; // {byte offset, width, height, component}
     const uint8_t* texels;
     uint32_t bvhCount;
@@ -190,6 +195,7 @@ struct Traffic {
     unsigned long long pNodeRounds, pNodeLanes, pLeafRounds, pLeafLanes, pTri2Lanes, pPops, pDeepPops;
     unsigned long long pNodeWaitLeaf, pNodeDone, pNodeNoRay, pLeafWaitNode, pLeafDone, pLeafNoRay, pLeafUpdates; // lanes that sit a round out, by reason (wave-uniform)
     unsigned long long pDirectInt, pPopInt; // (per lane) steps that leave the lane on an internal record outside the hot set: reached by descending from its parent / by a pop
+    unsigned long long pAlphaRounds, pAlphaCycles; // (wave-uniform) cooperative leaf rounds in which a candidate looked its alpha record up, and the cycles from the candidate test to the end of the alpha tests
     unsigned long long pNodeDistinct; // distinct records the lanes of the node rounds asked for (wave-uniform): the coherence of a wave's rays
 #endif
 };
@@ -342,11 +348,12 @@ __device__ __forceinline__ float tri_intersect(const DevRay& r, Vec3 p0, Vec3 p1
 }
 
 // ---------------------------------------------------------------------------- textures (texture.cpp:31-183)
-__device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t component, Vec2 uv, int32_t width, int32_t height, bool soa)
+// The cell of the bilinear tap at uv: (x0, y0) as bilinear() below computes them and the in-cell coordinates xt, yt.  False when
+// uv is not finite (then the blend's weights are NaN in one of the reference's two flavours and the caller takes the full path).
+__device__ __forceinline__ bool bilinear_cell(Vec2 uv, int32_t width, int32_t height, bool soa, int32_t& x0, int32_t& y0, float& xt, float& yt)
 {
     float s = uv.x - floorf(uv.x);
     float t = uv.y - floorf(uv.y);
-    float xt, yt;
     if (soa) {
         xt = sse_max(s * (float)width - 0.5f, 0.0f);
         yt = sse_max(t * (float)height - 0.5f, 0.0f);
@@ -354,15 +361,24 @@ __device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t com
         xt = std_max(s * (float)width - 0.5f, 0.0f);
         yt = std_max(t * (float)height - 0.5f, 0.0f);
     }
-    int32_t x0 = (int32_t)floorf(xt), y0 = (int32_t)floorf(yt);
+    x0 = (int32_t)floorf(xt);
+    y0 = (int32_t)floorf(yt);
+    return s == s && t == t;
+}
+
+__device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t component, Vec2 uv, int32_t width, int32_t height, bool soa)
+{
+    float xt, yt;
+    int32_t x0, y0;
+    (void)bilinear_cell(uv, width, height, soa, x0, y0, xt, yt);
     int32_t x1 = (x0 + 1 < width - 1) ? x0 + 1 : width - 1;
     int32_t y1 = (y0 + 1 < height - 1) ? y0 + 1 : height - 1;
     idx[0] = component * (x0 + y0 * width);
     idx[1] = component * (x1 + y0 * width);
     idx[2] = component * (x0 + y1 * width);
     idx[3] = component * (x1 + y1 * width);
-    s = xt - (float)x0;
-    t = yt - (float)y0;
+    const float s = xt - (float)x0;
+    const float t = yt - (float)y0;
     k[0] = (1.0f - s) * (1.0f - t);
     k[1] = s * (1.0f - t);
     k[2] = (1.0f - s) * t;
@@ -370,9 +386,8 @@ __device__ __forceinline__ void bilinear(float k[4], int32_t idx[4], int32_t com
 }
 
 template <bool COUNT>
-__device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint32_t tex, Vec2 uv, bool soa, Traffic& tr)
+__device__ __forceinline__ bool tex_test_alpha(const DevScene& sc, uint4 d, Vec2 uv, bool soa, Traffic& tr)
 {
-    uint4 d = gld4u(&sc.texDesc[tex]);
     const uint8_t* p = sc.texels + d.x;
     float k[4];
     int32_t idx[4];
@@ -550,11 +565,11 @@ __device__ __forceinline__ bool tri_candidate(const DevScene& sc, uint32_t tri, 
     if (!(t >= 0.0001f && t < limit)) return false;
     const uint32_t alphaRef = leafHasAlpha ? gld(sc.triAlpha + tri) : 0u;
     if (alphaRef) {
-        const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
-        float4 u0 = gld4(ap), u1 = gld4(ap + 1);
+        const float4* ap = sc.alpha + 3 * (size_t)(alphaRef - 1);
+        float4 u0 = gld4(ap), u1 = gld4(ap + 1), u2 = gld4(ap + 2);
         // i*uv0 + j*uv1 + k*uv2 (bvh.cpp:336, 407)
         Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y};
-        if (!tex_test_alpha<COUNT>(sc, asu(u1.z), uv, PACKET, tr)) return false;
+        if (!tex_test_alpha<COUNT>(sc, make_uint4(asu(u2.x), asu(u2.y), asu(u2.z), asu(u2.w)), uv, PACKET, tr)) return false;
     }
     if (!OCCLUDE) {
         hit.t = t;
@@ -946,17 +961,42 @@ __device__ __forceinline__ void tracer_leaf_coop(const DevScene& sc, Tracer& T, 
     float t = -1.0f, bi = 0.0f, bj = 0.0f, bk = 0.0f;
     uint32_t primId = 0u;
     bool cand = false;
+#ifdef PRT_PROFILE
+    unsigned long long pAlpha0 = 0;
+#endif
     if (pair) {
         t = tri_intersect(r, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), bi, bj, bk);
         primId = tri; // the LEAF-ORDER index (tri_candidate)
         cand = t >= 0.0001f && t < limit;
+#ifdef PRT_PROFILE
+        pAlpha0 = __builtin_amdgcn_s_memtime();
+#endif
+        // The alpha test of a candidate (bvh.cpp:336-338, 407-409) is a chain of dependent fetches that one or two lanes of the round walk
+        // while the others wait (profile build: a quarter of C3's leaf rounds, a whole round's time each): the record carries its
+        // texture's descriptor, and most tests end at the class of the tap's cell -- one word of a map that stays in the L2 -- instead
+        // of four texel fetches.
         const uint32_t alphaRef = (cand && (flags & 4u)) ? gld(sc.triAlpha + tri) : 0u;
         if (alphaRef) {
-            const float4* ap = sc.alpha + 2 * (size_t)(alphaRef - 1);
-            const float4 u0 = gld4(ap), u1 = gld4(ap + 1);
+            const float4* ap = sc.alpha + 3 * (size_t)(alphaRef - 1);
+            const float4 u0 = gld4(ap), u1 = gld4(ap + 1), u2 = gld4(ap + 2);
             const Vec2 uv = Vec2{bi * u0.x + bj * u0.z + bk * u1.x, bi * u0.y + bj * u0.w + bk * u1.y}; // bvh.cpp:336, 407
-            cand = tex_test_alpha<false>(sc, asu(u1.z), uv, PACKET, tr);
+            const uint4 d = make_uint4(asu(u2.x), asu(u2.y), asu(u2.z), asu(u2.w));
+            int32_t x0, y0;
+            float xt, yt;
+            uint32_t cls = 0u;
+            if (bilinear_cell(uv, (int32_t)d.y, (int32_t)d.z, PACKET, x0, y0, xt, yt)) {
+                const uint32_t cell = (uint32_t)x0 + (uint32_t)y0 * d.y;
+                cls = (gld(sc.alphaClass + asu(u1.w) + (cell >> 4)) >> ((cell & 15u) * 2u)) & 3u;
+            }
+            if (cls == 0u) cand = tex_test_alpha<false>(sc, d, uv, PACKET, tr); // a cell with texels on both sides of the threshold, or a non-finite uv
+            else cand = cls == 1u;
         }
+#ifdef PRT_PROFILE
+        if (__ballot(cand && (flags & 4u)) != 0ull) { // (ballot of the lanes inside `if (pair)`: some candidate lies in a leaf with alpha-tested triangles)
+            tr.pAlphaRounds++;
+            tr.pAlphaCycles += __builtin_amdgcn_s_memtime() - pAlpha0;
+        }
+#endif
     }
     const unsigned long long acc = __ballot(cand);
     // ---- owners

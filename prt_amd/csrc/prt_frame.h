@@ -931,6 +931,8 @@ __device__ PRT_ROLE_INLINE void trace_queue(uint64_t kargs)
         atomicAdd(&C[69 + MODE * 8], tr.pLeafNoRay);
         atomicAdd(&C[70 + MODE * 8], tr.pLeafUpdates);
         atomicAdd(&C[71 + MODE * 8], tr.pNodeDistinct);
+        atomicAdd(&C[122], tr.pAlphaRounds);
+        atomicAdd(&C[123], tr.pAlphaCycles >> 10);
         atomicAdd(&C[120], directInt);
         atomicAdd(&C[121], popInt);
         atomicAdd(&C[37 + MODE * 8], pRefillLanes);

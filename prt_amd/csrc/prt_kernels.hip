@@ -561,6 +561,8 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     std::vector<float4> wnodes, shade, bump, mats, alpha;
     std::vector<float> tris;                 // 9 floats per triangle, leaf order
     std::vector<uint32_t> triAlpha, triPrim; // per triangle, leaf order
+    std::vector<uint32_t> alphaClass;        // 2 bits per bilinear cell of every alpha-tested texture (prt_device.h DevScene::alphaClass)
+    std::vector<uint32_t> classWordOf;       // per texture: first word of its cell classes in alphaClass, 0xffffffff = not built yet
     std::vector<uint4> texDesc;
     std::vector<uint8_t> texels;
     DevScene sc{};
@@ -575,6 +577,32 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
         memcpy(&texels[off], td.texels, sz);
         texDesc.push_back(make_uint4((uint32_t)off, (uint32_t)td.width, (uint32_t)td.height, (uint32_t)td.component));
     }
+
+    classWordOf.assign(s->textureCount, 0xffffffffu);
+    // Cell classes of texture t (built when the first alpha-tested material names it).  The tap of Texture::testAlpha at a uv in cell
+    // (x0, y0) blends the alpha bytes of (x0, y0), (x1, y0), (x0, y1), (x1, y1), x1 = min(x0 + 1, w - 1), with weights >= 0 that sum to 1
+    // up to rounding (texture.cpp:31-100): four bytes >= 128 give more than 127 whatever the weights, four bytes <= 126 give less
+    // (the blend is off 128 x sum(k) by < 1e-4); a cell with a byte of 127, or with bytes on both sides, is left to the blend itself.
+    auto classWord = [&](uint32_t t) -> uint32_t {
+        if (classWordOf[t] != 0xffffffffu) return classWordOf[t];
+        const uint4 d = texDesc[t];
+        const int32_t w = (int32_t)d.y, h = (int32_t)d.z, comp = (int32_t)d.w;
+        const uint8_t* px = texels.data() + d.x;
+        const uint32_t first = (uint32_t)alphaClass.size();
+        alphaClass.resize(first + ((size_t)w * h + 15) / 16, 0u);
+        for (int32_t y0 = 0; y0 < h; y0++) {
+            const int32_t y1 = (y0 + 1 < h - 1) ? y0 + 1 : h - 1;
+            for (int32_t x0 = 0; x0 < w; x0++) {
+                const int32_t x1 = (x0 + 1 < w - 1) ? x0 + 1 : w - 1;
+                const uint32_t a[4] = {px[comp * (x0 + y0 * w) + 3], px[comp * (x1 + y0 * w) + 3], px[comp * (x0 + y1 * w) + 3], px[comp * (x1 + y1 * w) + 3]};
+                const uint32_t lo = std::min(std::min(a[0], a[1]), std::min(a[2], a[3])), hi = std::max(std::max(a[0], a[1]), std::max(a[2], a[3]));
+                const uint32_t cls = lo >= 128u ? 1u : (hi <= 126u ? 2u : 0u);
+                const uint32_t cell = (uint32_t)x0 + (uint32_t)y0 * (uint32_t)w;
+                alphaClass[first + (cell >> 4)] |= cls << ((cell & 15u) * 2u);
+            }
+        }
+        return classWordOf[t] = first;
+    };
 
     bool anyBump = false;
     for (uint32_t m = 0; m < s->meshCount; m++)
@@ -678,9 +706,11 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
                     u[2] = md.texcoords[2 * v1]; u[3] = md.texcoords[2 * v1 + 1];
                     u[4] = md.texcoords[2 * v2]; u[5] = md.texcoords[2 * v2 + 1];
                 }
+                const uint4 ad = texDesc[mt.diffuseMap];
                 alpha.push_back(make_float4(u[0], u[1], u[2], u[3]));
-                alpha.push_back(make_float4(u[4], u[5], ubits((uint32_t)mt.diffuseMap), 0.0f));
-                alphaRef = (uint32_t)(alpha.size() / 2);
+                alpha.push_back(make_float4(u[4], u[5], ubits((uint32_t)mt.diffuseMap), ubits(classWord((uint32_t)mt.diffuseMap))));
+                alpha.push_back(make_float4(ubits(ad.x), ubits(ad.y), ubits(ad.z), ubits(ad.w)));
+                alphaRef = (uint32_t)(alpha.size() / 3);
             }
             HVec3 p0 = P(v0), p1 = P(v1), p2 = P(v2);
             const float corners[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
@@ -823,6 +853,7 @@ int prt_hip_upload_scene(prt_hip_ctx* c, const prt_scene_desc* s)
     if ((rc = upload_vec(c, bump, &sc.bump))) return rc;
     if ((rc = upload_vec(c, mats, &sc.mats))) return rc;
     if ((rc = upload_vec(c, alpha, &sc.alpha))) return rc;
+    if ((rc = upload_vec(c, alphaClass, &sc.alphaClass))) return rc;
     if ((rc = upload_vec(c, texDesc, &sc.texDesc))) return rc;
     if ((rc = upload_vec(c, texels, &sc.texels))) return rc;
     c->sc = sc;
@@ -1173,6 +1204,8 @@ int prt_hip_get_stats(prt_hip_ctx* c, prt_hip_stats* st)
                     h[118] / 1e6, (double)h[119] / h[118], 4.0 * h[8] / h[13]);
         fprintf(stderr, "  node steps that leave a lane on an internal record outside the hot set: %.2f G by descending from the parent, %.2f G by a pop (%.2f of them direct)\n",
                 h[120] / 1e9, h[121] / 1e9, (double)h[120] / (double)(h[120] + h[121] ? h[120] + h[121] : 1));
+        fprintf(stderr, "  cooperative leaf rounds in which a candidate of a leaf with alpha-tested triangles came up: %.1f M, %.0f cycles each from the candidate test to the end of the alpha tests = %.1f Gcycles of wave time\n",
+                h[122] / 1e6, h[123] * 1024.0 / (double)(h[122] ? h[122] : 1), h[123] * 1024.0 / 1e9);
         fprintf(stderr, "  stack pops of modes 1-3: %.1f G, of them from the spill area in HBM: %.2f G\n", (h[32 + 15] + h[32 + 23] + h[32 + 31]) / 1e9, h[39] / 1e9);
         fprintf(stderr, "  claims %.1f M, empty %.1f M; shade passes %.1f M with %.2f groups each\n", h[28] / 1e6, h[29] / 1e6, h[30] / 1e6, (double)h[31] / (double)(h[30] ? h[30] : 1));
     }
