@@ -196,7 +196,10 @@ int prt_hip_comm_destroy(prt_hip_ctx* ctx);
 /* Collective, after prt_hip_render(..., params.rank = the communicator's rank, params.nranks = its size, d_rgb, stream) on every
  * rank: grouped ncclSend (owners) / ncclRecv (root), so that each link into the root carries one peer's tiles, then the
  * de-interleave kernel on the root.  d_rgb / stream as in prt_hip_render (the same buffer the render wrote); afterwards the
- * root's buffer holds the whole image, the other ranks' buffers are unchanged. */
+ * root's buffer holds the whole image, the other ranks' buffers are unchanged.
+ * A failing ncclSend / ncclRecv returns PRT_HIP_ECOMM with the RCCL group closed again and marks the communicator BROKEN (RCCL leaves
+ * it in an error state): every later gather on this context is refused with PRT_HIP_ECOMM until prt_hip_comm_init or
+ * prt_hip_comm_adopt replaces it on every rank (a broken communicator the context owns is ended with ncclCommAbort). */
 int prt_hip_gather_rccl(prt_hip_ctx* ctx, float* d_rgb, int root, void* stream);
 /* bytes the context's rank contributes to a gather of its last render (what travels over xGMI) */
 int prt_hip_gather_payload_bytes(prt_hip_ctx* ctx, uint64_t* bytes);
