@@ -722,6 +722,65 @@ def test_rccl_gather_single_rank_communicator(tracer, c1):
         t.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_alpha_cell_classes_at_the_threshold_bytes(tracer, tmp_path, seed):
+    """The cooperative leaf rounds decide most alpha tests from a 2-bit class per bilinear cell (prt_device.h DevScene::alphaClass:
+    four texels >= 128 pass, four <= 126 fail, anything else takes Texture::testAlpha's blend, texture.cpp:31-100).  An alpha map
+    made of blocks whose bytes sit ON the threshold -- 125, 126, 127, 128, 129 beside 0 and 255, plus blocks of per-texel noise
+    from the same set -- so that cells of every class, and cells whose four texels are all 127 (the blend gives exactly 127: fails)
+    or straddle 126 / 128, are hit by thousands of candidates; uv inside and far outside [0, 1]; scatter, packet-occlusion and
+    single-occlusion rays (directional light).  Image and ray counts equal the oracle's bit for bit, in the timed build (the cell
+    classes) and in the counting build (the serial leaf form: the blend every time)."""
+    from test_host_cpu import _png
+    rng = np.random.default_rng(9100 + seed)
+    td = str(tmp_path)
+    bw, bh = int(rng.integers(5, 9)), int(rng.integers(4, 8))
+    w, h = 8 * bw + int(rng.integers(0, 5)), 8 * bh + int(rng.integers(0, 5))   # not multiples of the block size
+    vals = np.array([0, 125, 126, 127, 128, 129, 255], dtype=np.uint8)
+    a = rng.integers(0, 256, size=(h, w, 4)).astype(np.uint8)
+    for by in range(0, h, 8):
+        for bx in range(0, w, 8):
+            blk = a[by:by + 8, bx:bx + 8, 3]
+            if rng.random() < 0.25:
+                blk[...] = vals[rng.integers(0, len(vals), size=blk.shape)]     # noise on the threshold
+            else:
+                blk[...] = vals[int(rng.integers(0, len(vals)))]                # a flat block
+    _png(os.path.join(td, "mask.png"), a, level=6)
+    with open(os.path.join(td, "m.mtl"), "w") as f:
+        f.write("newmtl holes\nKd 0.9 0.9 0.9\nmap_Kd mask.png\nnewmtl wall\nKd 0.7 0.6 0.5\n")
+    n = 160
+    centre = rng.uniform(-1, 1, size=(n, 1, 3))
+    size = np.exp(rng.uniform(np.log(0.15), np.log(0.9), size=(n, 1, 1)))
+    tri = centre + size * rng.normal(size=(n, 3, 3))
+    uv = rng.uniform(-2.5, 3.5, size=(n, 3, 2)) if seed % 2 else rng.uniform(0, 1, size=(n, 3, 2))
+    with open(os.path.join(td, "s.obj"), "w") as f:
+        f.write("mtllib m.mtl\n")
+        for t in tri.reshape(-1, 3):
+            f.write("v %.9g %.9g %.9g\n" % tuple(t))
+        for t in uv.reshape(-1, 2):
+            f.write("vt %.9g %.9g\n" % tuple(t))
+        for k in range(n):
+            f.write("usemtl %s\n" % ("holes" if k % 4 else "wall"))
+            i = 3 * k + 1
+            f.write(f"f {i}/{i} {i + 1}/{i + 1} {i + 2}/{i + 2}\n")
+    mesh = prt_amd.Mesh.load_obj(os.path.join(td, "s.obj"))
+    mesh.calculate_bounds()
+    scene = prt_amd.Scene()
+    scene.add(mesh)
+    assert int(scene.arrays()["meshes"][0]["materials"]["alphaTest"].sum()) == 1
+    scene.set_directional_light((0.3, 0.5, 0.81), (6.0, 5.0, 4.0))
+    W, H = 96, 64
+    camera = prt_amd.Camera().create((0.1, -0.05, 3.4), (-0.02, 0.01, -1.0), W, H)
+    upload(tracer, scene, camera)
+    osc = T.OracleScene(T.scene_desc_from_product(scene, camera, 1.0))
+    ref, ost = osc.render(32, max_depth=6)
+    for count in (False, True):
+        img = tracer.render(32, max_depth=6, count_traffic=count)
+        st = tracer.last_stats
+        assert_bits_equal(img, ref, "alpha map on the threshold, " + ("counting" if count else "timed") + " build")
+        assert st["raysTraced"] == ost["raysTraced"] and st["occludedTraced"] == ost["occludedTraced"]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 6, 9])
 def test_textured_obj_scenes_through_the_asset_loaders(tracer, tmp_path, seed):
     """SURVEY 8f.2 on the GPU: a scene that reaches the kernels THROUGH THE ASSET LOADERS -- a triangle soup written as OBJ + MTL with
