@@ -952,3 +952,27 @@ def test_reference_main_cpp_compiles_and_links_unmodified(L, tmp_path):
         syms = subprocess.check_output(["nm", "-u", "-C", str(exe)]).decode()
         for needed in ("prt::PathTracer::TraceBlock", "prt::Bvh::build", "prt::Scene::add", "prt::Image::saveExr", "prt::ThreadPool::queue"):
             assert needed in syms, needed
+
+
+def test_bench_roofline_binds_on_a_measured_roof_of_the_committed_counters():
+    """bench.py's `roofline.frac` is the LARGEST of three measured roofs (useful vector-ALU share, L2-miss rate against the measured gather
+    ceiling of the tree's size, HBM bytes), each <= 1, from the committed counter summary of the workload -- never the algorithmic figure,
+    which exceeds 1 on the headline configuration.  The summaries under profiles/ must carry the stamp of the kernel
+    sources in the tree: bench.py ignores a stale one and would then report `frac: null` to the driver."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    expect = {"c3": ("valu_useful", 13.3e6), "c4": ("l2_miss_rate", 127.7e6), "c5share": ("l2_miss_rate", 255e6)}
+    for w, (bound, tree) in expect.items():
+        ev = json.load(open(os.path.join(root, "profiles", f"r04_frame_{w}_counters.json")))
+        assert ev["source_sha16"] == prt_amd.source_sha16(), f"profiles/r04_frame_{w}_counters.json was taken with other kernel sources: collect it again (tools/collect_counters.sh)"
+        name, roofs = bench.binding_roof(ev, ev["kernel_ms_under_profiler_median"], tree)
+        assert name == bound, (w, name)
+        assert all(0.0 < r["frac"] <= 1.0 for r in roofs.values()), (w, {k: r["frac"] for k, r in roofs.items()})
+        assert roofs[name]["frac"] == max(r["frac"] for r in roofs.values())
+    # the table of gather ceilings is monotone in the table size
+    sizes = [g for _, g, _ in bench.GATHER_ROOF]
+    assert sizes == sorted(sizes, reverse=True)
